@@ -1,0 +1,118 @@
+"""ctypes binding of libcm3p_hip.so (declared in include/cm3p_hip.h).
+
+This is the only place the C ABI is crossed.  Every wrapper passes raw device pointers (`tensor.data_ptr()`), sizes
+and the current HIP stream, checks the integer return code and raises on failure.  There is no CPU fallback: if the
+library cannot be loaded, or a tensor is not on a GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+EPI_BF16, EPI_F32, EPI_F32_RESID = 0, 1, 2
+ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcm3p_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, mirrors include/cm3p_hip.h one to one
+SIGNATURES = {
+    "cm3p_abi_version": [],
+    "cm3p_layernorm_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "cm3p_layernorm_bwd_blocks": [_L],
+    "cm3p_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "cm3p_embed_ln_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
+    "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _P],
+    "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
+    "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
+    "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
+    "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],
+    "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
+    "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
+    "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
+    "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],
+    "cm3p_gelu_fwd": [_P, _P, _L, _P],
+    "cm3p_gelu_bwd": [_P, _P, _P, _L, _P],
+    "cm3p_pool_chunks": [_I],
+    "cm3p_pool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cm3p_pool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "cm3p_gemm_f32": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _F, _I, _P],
+    "cm3p_l2norm_fwd": [_P, _P, _P, _I, _I, _P],
+    "cm3p_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "cm3p_cross_entropy": [_P, _I, _I, _L, _L, _P, _P, _F, _P, _P, _P],
+    "cm3p_first_zero_index": [_P, _I, _I, _P, _P],
+    "cm3p_scale_exp": [_P, _P, _P, _L, _P],
+    "cm3p_dot_f32": [_P, _P, _P, _L, _P],
+    "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
+}
+
+_lib = None
+
+
+class Cm3pHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the kernel library (once) and attach the prototypes.  Raises if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Cm3pHipError(
+            f"{LIB_PATH} not found: build it with `python -m cm3p_amd.build` (or __graft_entry__.build()). "
+            "cm3p_amd has no CPU or PyTorch fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.cm3p_abi_version() != ABI_VERSION:
+        raise Cm3pHipError(f"ABI mismatch: library {lib.cm3p_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise Cm3pHipError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise Cm3pHipError("cm3p_amd kernels need GPU tensors; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise Cm3pHipError("cm3p_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise Cm3pHipError(f"unsupported dtype {t.dtype}")
+
+
+def call(name: str, *args):
+    _check(getattr(load(), name)(*args), name)
+
+
+def query(name: str, *args) -> int:
+    """Host-only helpers that return a size, not an error code."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,586 @@
+// Non-causal flash attention for ModernBERT's global and sliding-window layers, head_dim 64, gfx950.
+//
+// Replaces F.scaled_dot_product_attention(q, k, v, attn_mask, scale, is_causal=False)
+// (TF:integrations/sdpa_attention.py:153-163, called from TF:models/modernbert/modeling_modernbert.py:286-297)
+// and the (B,1,S,S) boolean mask the reference materialises for it (TF:masking_utils.py:141-151,168-179):
+//     visible(b, q, kv) = key_mask[b, kv] AND (window < 0 OR |q - kv| <= window)
+// Nothing S x S is ever stored: the rule is evaluated per score inside the kernels, and sliding-window layers only
+// visit the key tiles that intersect the band.
+//
+// Layout: packed qkv [B, S, 3, nh, 64] bf16 (q, k already rotated), out [B, S, nh, 64] bf16, lse [B, nh, S] fp32.
+//
+// MFMA formulation (v_mfma_f32_32x32x16_bf16, one wave = 32 queries or 32 keys):
+//   forward  S^T = K Q^T (key rows in registers, query on the lane)  ->  softmax statistics are per-lane scalars;
+//            O^T += V^T P^T, where P^T is fed to the MFMA straight from the S^T accumulators (no LDS round trip) and
+//            V^T comes from ds_read_b64_tr_b16 (hardware transpose) of the row-major V tile.
+//   dq       recompute S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta); dQ^T += K^T dS^T (K^T by transposed reads).
+//   dk, dv   key on the lane: S = Q K^T, dP = dO V^T with -lse/scale and -delta preloaded as the initial accumulators;
+//            dV^T += dO^T P and dK^T += Q^T dS consume the accumulators directly as B operands.
+// LDS images (128-byte rows): "R" for ds_read_b128 row fragments (16-byte chunk index XOR (row>>1)&7) and "T" for
+// transposed reads (32-byte segment index XOR 2*((row>>1)&1)); both are bank-conflict free for these access shapes.
+#include "common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+__device__ __forceinline__ int off_R(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int off_T(int row, int col) {
+    return row * 128 + ((((col >> 4) ^ (((row >> 1) & 1) << 1)) & 3) << 5) + ((col & 15) << 1);
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// A-operand fragment of X^T (rows = the 64 columns of tile X, k = 16 rows of X starting at krow0) for the product
+// X^T * Y where Y comes from accumulators: element j of lane half hh is row krow0 + 8*(j>>2) + 4*hh + (j&3) of X.
+// `cblk` selects columns 32*cblk .. 32*cblk+31 of X (the MFMA's 32 output rows).
+__device__ __forceinline__ bf16x8 frag_T(const char* tile, int krow0, int cblk, int lane) {
+    const int g = lane >> 4, hh = g >> 1, i = lane & 15;
+    const int row = krow0 + 4 * hh + (i >> 2);
+    const int col = 32 * cblk + 16 * (g & 1) + 4 * (i & 3);
+    const bf16x4 lo = lds_read_tr16(tile + off_T(row, col));
+    const bf16x4 hi = lds_read_tr16(tile + off_T(row + 8, col));
+    return cat_bf16x4(lo, hi);
+}
+
+// Row fragment (A or B operand): lane holds X[row0 + (lane&31)][16*s + 8*(lane>>5) + j]
+__device__ __forceinline__ bf16x8 frag_R(const char* tile, int row0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + off_R(row0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+
+// accumulator registers 8*sp .. 8*sp+7 -> bf16 B-operand fragment for k-step sp
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sp) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * sp + j];
+    return r;
+}
+
+struct TileRegs64 {  // a 64-row x 64-col bf16 tile spread over 256 threads: 2 x 16 bytes each
+    uint4 v[2];
+};
+
+// rows r0 .. r0+63 of a [*, 64] bf16 matrix with row stride `ld` elements; rows >= limit read as zero
+__device__ __forceinline__ void gload64(TileRegs64& t, const uint16_t* base, int64_t ld, int r0, int limit, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+        const int r = r0 + row;
+        t.v[i] = (r < limit && r >= 0) ? *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + c * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+}
+__device__ __forceinline__ void lstore64_R(char* tile, const TileRegs64& t, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+        *reinterpret_cast<uint4*>(tile + off_R(row, c)) = t.v[i];
+    }
+}
+__device__ __forceinline__ void lstore64_T(char* tile, const TileRegs64& t, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
+        *reinterpret_cast<uint4*>(tile + off_T(row, c * 8)) = t.v[i];
+    }
+}
+
+__device__ __forceinline__ float reg_max16(const f32x16& a) {
+    float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+    float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+    float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
+// visibility of keys (tile key0 + 32*blk + rows of the accumulator) for this lane's query `qrow`
+// maskb: 64 bytes of key validity for the tile in LDS.  Sets invisible scores to -inf.
+__device__ __forceinline__ void mask_scores_keyrows(f32x16& s, const uint8_t* maskb, int blk, int key0, int qrow, int window,
+                                                    int hh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int kl = 32 * blk + 8 * g + 4 * hh;
+        const uint32_t mb = *reinterpret_cast<const uint32_t*>(maskb + kl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kl + r;
+            const int dist = qrow > key ? qrow - key : key - qrow;
+            const bool ok = ((mb >> (8 * r)) & 0xffu) != 0u && (window < 0 || dist <= window);
+            if (!ok) s[4 * g + r] = kNegInf;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: one workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 64 keys, double buffered.
+// LDS per stage: K image R (8 KiB) + V image T (8 KiB) + 64 mask bytes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFwdStage = 8192 + 8192 + 64;
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                          float* __restrict__ lse, const uint8_t* __restrict__ kmask, int S,
+                                                          int nh, int window, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int Q0 = blockIdx.x * 128;
+    const int q0 = Q0 + wid * 32;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const bool masked = (kmask != nullptr) || window >= 0 || (S % 64 != 0);
+
+    const int qrow = q0 + (lane & 31);
+    const int qrow_c = qrow < S ? qrow : S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+
+    const int Q1 = min(S, Q0 + 128) - 1;
+    int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
+    if (window >= 0) {
+        klo = max(0, Q0 - window);
+        khi = min(S - 1, Q1 + window);
+        wlo = max(0, q0 - window);
+        whi = min(S - 1, q0 + 31 + window);
+    }
+    const bool wave_live = q0 < S;
+    const int t_lo = klo / 64, t_hi = khi / 64;
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
+    float m_run = kNegInf, l_run = 0.f;
+    const float c = scale * kLog2e;
+
+    TileRegs64 kr, vr;
+    uint8_t mreg = 0;
+    auto gload = [&](int t) {
+        gload64(kr, kbase, ld, t * 64, S, tid);
+        gload64(vr, vbase, ld, t * 64, S, tid);
+        if (tid < 64) {
+            const int key = t * 64 + tid;
+            mreg = key < S ? (kmask ? kmask[(int64_t)b * S + key] : (uint8_t)1) : (uint8_t)0;
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* st = smem + stage * kFwdStage;
+        lstore64_R(st, kr, tid);
+        lstore64_T(st + 8192, vr, tid);
+        if (tid < 64) reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
+    };
+
+    gload(t_lo);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int stage = (t - t_lo) & 1;
+        const char* st = smem + stage * kFwdStage;
+        const bool more = t < t_hi;
+        if (more) gload(t + 1);
+
+        const int key0 = t * 64;
+        if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
+            f32x16 sacc[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
+            }
+            if (masked) {
+                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
+                mask_scores_keyrows(sacc[0], mb, 0, key0, qrow, window, hh);
+                mask_scores_keyrows(sacc[1], mb, 1, key0, qrow, window, hh);
+            }
+            float mt = fmaxf(reg_max16(sacc[0]), reg_max16(sacc[1]));
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt);
+            const float mc = (m_new == kNegInf) ? 0.f : m_new * c;
+            const float alpha = __builtin_amdgcn_exp2f(m_run * c - mc);  // m_run = -inf -> 0
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i] * c - mc);
+                    sacc[blk][i] = p;
+                    psum += p;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 pf = acc_to_frag(sacc[s >> 1], s & 1);
+                oacc[0] = mfma32(frag_T(st + 8192, 16 * s, 0, lane), pf, oacc[0]);
+                oacc[1] = mfma32(frag_T(st + 8192, 16 * s, 1, lane), pf, oacc[1]);
+            }
+        }
+        if (more) lstore(stage ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < S) {
+        uint16_t* orow = out + ((int64_t)b * S + qrow) * nh * 64 + head * 64;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dv = 32 * blk + 8 * g + 4 * hh;
+                const uint2 w = {pack_bf16x2(oacc[blk][4 * g] * inv, oacc[blk][4 * g + 1] * inv),
+                                 pack_bf16x2(oacc[blk][4 * g + 2] * inv, oacc[blk][4 * g + 3] * inv)};
+                *reinterpret_cast<uint2*>(orow + dv) = w;
+            }
+        if (hh == 0)
+            lse[((int64_t)b * nh + head) * S + qrow] = l_tot > 0.f ? m_run * scale + __logf(l_tot) : __builtin_huge_valf();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// delta[b, h, q] = sum_d dO[q, d] * O[q, d]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
+                                                         float* __restrict__ delta, int64_t T, int S, int nh) {
+    const int64_t total = T * nh * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total + 7; i += (int64_t)gridDim.x * 256) {
+        const bool ok = i < total;
+        const int64_t row = ok ? i >> 3 : 0;  // (token, head)
+        const int c = (int)(i & 7);
+        float s = 0.f;
+        if (ok) {
+            const uint4 a = *reinterpret_cast<const uint4*>(o + row * 64 + c * 8);
+            const uint4 g = *reinterpret_cast<const uint4*>(d_o + row * 64 + c * 8);
+            s = bf16lo(a.x) * bf16lo(g.x) + bf16hi(a.x) * bf16hi(g.x) + bf16lo(a.y) * bf16lo(g.y) + bf16hi(a.y) * bf16hi(g.y) +
+                bf16lo(a.z) * bf16lo(g.z) + bf16hi(a.z) * bf16hi(g.z) + bf16lo(a.w) * bf16lo(g.w) + bf16hi(a.w) * bf16hi(g.w);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (ok && c == 0) {
+            const int64_t tok = row / nh;
+            const int h = (int)(row % nh);
+            delta[((tok / S) * nh + h) * S + tok % S] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dQ: same geometry as the forward.  LDS per stage: K image R + K image T + V image R + mask bytes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDqStage = 3 * 8192 + 64;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                             int S, int nh, int window, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int Q0 = blockIdx.x * 128;
+    const int q0 = Q0 + wid * 32;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + (int64_t)b * S * ldo + head * 64;
+
+    const int qrow = q0 + (lane & 31);
+    const int qrow_c = qrow < S ? qrow : S - 1;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+        dof[s] = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+    }
+    const float c = scale * kLog2e;
+    const int64_t stat = ((int64_t)b * nh + head) * S + qrow_c;
+    const float lse2 = lse[stat] * kLog2e;  // +inf for rows with no visible key -> p = 0
+    const float dlt = delta[stat];
+
+    const int Q1 = min(S, Q0 + 128) - 1;
+    int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
+    if (window >= 0) {
+        klo = max(0, Q0 - window);
+        khi = min(S - 1, Q1 + window);
+        wlo = max(0, q0 - window);
+        whi = min(S - 1, q0 + 31 + window);
+    }
+    const bool wave_live = q0 < S;
+    const int t_lo = klo / 64, t_hi = khi / 64;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
+
+    TileRegs64 kr, vr;
+    uint8_t mreg = 0;
+    auto gload = [&](int t) {
+        gload64(kr, kbase, ld, t * 64, S, tid);
+        gload64(vr, vbase, ld, t * 64, S, tid);
+        if (tid < 64) {
+            const int key = t * 64 + tid;
+            mreg = key < S ? (kmask ? kmask[(int64_t)b * S + key] : (uint8_t)1) : (uint8_t)0;
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* st = smem + stage * kDqStage;
+        lstore64_R(st, kr, tid);
+        lstore64_T(st + 8192, kr, tid);
+        lstore64_R(st + 16384, vr, tid);
+        if (tid < 64) reinterpret_cast<uint8_t*>(st + 24576)[tid] = mreg;
+    };
+
+    gload(t_lo);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int stage = (t - t_lo) & 1;
+        const char* st = smem + stage * kDqStage;
+        const bool more = t < t_hi;
+        if (more) gload(t + 1);
+        const int key0 = t * 64;
+        if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
+            f32x16 sacc[2], dp[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[blk][i] = dp[blk][i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
+                    dp[blk] = mfma32(frag_R(st + 16384, 32 * blk, s, lane), dof[s], dp[blk]);
+                }
+            }
+            const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 24576);
+            mask_scores_keyrows(sacc[0], mb, 0, key0, qrow, window, hh);
+            mask_scores_keyrows(sacc[1], mb, 1, key0, qrow, window, hh);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i] * c - lse2);
+                    sacc[blk][i] = p * (dp[blk][i] - dlt) * scale;  // dS^T
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 dsf = acc_to_frag(sacc[s >> 1], s & 1);
+                dq[0] = mfma32(frag_T(st + 8192, 16 * s, 0, lane), dsf, dq[0]);
+                dq[1] = mfma32(frag_T(st + 8192, 16 * s, 1, lane), dsf, dq[1]);
+            }
+        }
+        if (more) lstore(stage ^ 1);
+        __syncthreads();
+    }
+
+    if (qrow < S) {
+        uint16_t* drow = dqkv + ((int64_t)b * S + qrow) * ld + head * 64;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * blk + 8 * g + 4 * hh;
+                const uint2 w = {pack_bf16x2(dq[blk][4 * g], dq[blk][4 * g + 1]), pack_bf16x2(dq[blk][4 * g + 2], dq[blk][4 * g + 3])};
+                *reinterpret_cast<uint2*>(drow + d) = w;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dK, dV: one workgroup = 4 waves = 128 keys of one (batch, head); each wave owns 32 keys (key on the lane) and keeps
+// dK^T, dV^T (64 x 32 each) in accumulators while the workgroup sweeps query tiles of 64 rows.
+// LDS per stage: Q image R + Q image T + dO image R + dO image T (8 KiB each) + lse/scale and delta (64 floats each).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDkvStage = 4 * 8192 + 512;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                              int S, int nh, int window, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int K0 = blockIdx.x * 128;
+    const int k0 = K0 + wid * 32;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + (int64_t)b * S * ldo + head * 64;
+    const float* lse_bh = lse + ((int64_t)b * nh + head) * S;
+    const float* dlt_bh = delta + ((int64_t)b * nh + head) * S;
+
+    const int krow = k0 + (lane & 31);
+    const int krow_c = krow < S ? krow : S - 1;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+        vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+    }
+    const bool key_ok = krow < S && (kmask ? kmask[(int64_t)b * S + krow] != 0 : true);
+    const float c = scale * kLog2e;
+    const float inv_scale = 1.0f / scale;
+
+    const int K1 = min(S, K0 + 128) - 1;
+    int qlo = 0, qhi = S - 1, wlo = 0, whi = S - 1;
+    if (window >= 0) {
+        qlo = max(0, K0 - window);
+        qhi = min(S - 1, K1 + window);
+        wlo = max(0, k0 - window);
+        whi = min(S - 1, k0 + 31 + window);
+    }
+    const bool wave_live = k0 < S;
+    const int t_lo = qlo / 64, t_hi = qhi / 64;
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
+
+    TileRegs64 qr, gr;
+    float sreg = 0.f;
+    auto gload = [&](int t) {
+        gload64(qr, qbase, ld, t * 64, S, tid);
+        gload64(gr, dobase, ldo, t * 64, S, tid);
+        if (tid < 128) {
+            const int q = t * 64 + (tid & 63);
+            if (tid < 64) sreg = q < S ? -lse_bh[q] * inv_scale : kNegInf;  // -lse/scale; rows past S contribute p = 0
+            else sreg = q < S ? -dlt_bh[q] : 0.f;
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* st = smem + stage * kDkvStage;
+        lstore64_R(st, qr, tid);
+        lstore64_T(st + 8192, qr, tid);
+        lstore64_R(st + 16384, gr, tid);
+        lstore64_T(st + 24576, gr, tid);
+        if (tid < 128) reinterpret_cast<float*>(st + 32768)[tid] = sreg;
+    };
+
+    gload(t_lo);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int stage = (t - t_lo) & 1;
+        const char* st = smem + stage * kDkvStage;
+        const bool more = t < t_hi;
+        if (more) gload(t + 1);
+        const int qt0 = t * 64;
+        if (wave_live && qt0 <= whi && qt0 + 63 >= wlo) {
+            const float* nlse = reinterpret_cast<const float*>(st + 32768);
+            const float* ndlt = nlse + 64;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {  // two 32-query blocks of the tile
+                f32x16 sacc, dp;
+                // initial accumulators: row constants -lse/scale and -delta (rows = queries)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 32 * qb + 8 * g + 4 * hh);
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(ndlt + 32 * qb + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sacc[4 * g + r] = a[r];
+                        dp[4 * g + r] = d[r];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);           // S - lse/scale, rows q, col key
+                    dp = mfma32(frag_R(st + 16384, 32 * qb, s, lane), vf[s], dp);       // dP - delta
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * g + r;
+                        const int q = qt0 + 32 * qb + 8 * g + 4 * hh + r;
+                        const int dist = q > krow ? q - krow : krow - q;
+                        const bool ok = key_ok && (window < 0 || dist <= window);
+                        const float p = ok ? __builtin_amdgcn_exp2f(sacc[i] * c) : 0.f;
+                        sacc[i] = p;
+                        dp[i] = p * dp[i] * scale;  // dS
+                    }
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const bf16x8 pf = acc_to_frag(sacc, sp);
+                    const bf16x8 dsf = acc_to_frag(dp, sp);
+                    const int r0 = 32 * qb + 16 * sp;
+                    dv[0] = mfma32(frag_T(st + 24576, r0, 0, lane), pf, dv[0]);
+                    dv[1] = mfma32(frag_T(st + 24576, r0, 1, lane), pf, dv[1]);
+                    dk[0] = mfma32(frag_T(st + 8192, r0, 0, lane), dsf, dk[0]);
+                    dk[1] = mfma32(frag_T(st + 8192, r0, 1, lane), dsf, dk[1]);
+                }
+            }
+        }
+        if (more) lstore(stage ^ 1);
+        __syncthreads();
+    }
+
+    if (krow < S) {
+        uint16_t* dkrow = dqkv + ((int64_t)b * S + krow) * ld + nh * 64 + head * 64;
+        uint16_t* dvrow = dkrow + nh * 64;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * blk + 8 * g + 4 * hh;
+                *reinterpret_cast<uint2*>(dkrow + d) =
+                    uint2{pack_bf16x2(dk[blk][4 * g], dk[blk][4 * g + 1]), pack_bf16x2(dk[blk][4 * g + 2], dk[blk][4 * g + 3])};
+                *reinterpret_cast<uint2*>(dvrow + d) =
+                    uint2{pack_bf16x2(dv[blk][4 * g], dv[blk][4 * g + 1]), pack_bf16x2(dv[blk][4 * g + 2], dv[blk][4 * g + 3])};
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
+                  float scale, void* stream) {
+    CM3P_REQUIRE(qkv && out && lse && B > 0 && S > 0 && nh > 0 && scale > 0.f);
+    CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
+    const dim3 grid((S + 127) / 128, nh, B);
+    attn_fwd_kernel<<<grid, 256, 2 * kFwdStage, static_cast<hipStream_t>(stream)>>>((const uint16_t*)qkv, (uint16_t*)out, lse,
+                                                                                   key_mask, S, nh, window, scale);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, void* stream) {
+    CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
+    CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t T = (int64_t)B * S;
+    int64_t blocks = (T * nh * 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    attn_delta_kernel<<<(int)blocks, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, T, S, nh);
+    CM3P_LAUNCH_CHECK();
+    const dim3 grid((S + 127) / 128, nh, B);
+    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                       key_mask, S, nh, window, scale);
+    CM3P_LAUNCH_CHECK();
+    attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                         key_mask, S, nh, window, scale);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+}  // extern "C"

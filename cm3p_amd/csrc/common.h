@@ -1,0 +1,62 @@
+// Shared device helpers for the CM3P gfx950 kernels.  CDNA4 only: 64-lane waves, MFMA, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cm3p_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CM3P_WAVE 64
+
+// Every extern "C" entry point ends with this: kernels never throw, launch errors become a return code.
+#define CM3P_LAUNCH_CHECK()                                         \
+    do {                                                            \
+        hipError_t e__ = hipGetLastError();                         \
+        if (e__ != hipSuccess) return CM3P_ERR_LAUNCH;              \
+    } while (0)
+
+#define CM3P_REQUIRE(cond)                   \
+    do {                                     \
+        if (!(cond)) return CM3P_ERR_INVALID; \
+    } while (0)
+
+static inline bool cm3p_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+
+// packs two floats into one dword of two bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserving)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, reads a 4-row x 16-column block of 16-bit elements and returns it
+// column-major (lane i of the group gets column i, rows 0..3).  `p` is this lane's own address: lane 4q+r of the
+// group supplies row q, columns 4r..4r+3.  EXEC must be all ones.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+__device__ __forceinline__ bf16x8 cat_bf16x4(bf16x4 a, bf16x4 b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}

@@ -1,0 +1,343 @@
+// HBM-bound elementwise / small-reduction kernels of the encoder: casts, RoPE, GeGLU, GELU, pooling.
+// 16-byte accesses per lane, grid capped at 2048 blocks with grid-stride loops (256 CUs x 8 blocks).
+//
+// Math restated from:
+//   TF:models/modernbert/modeling_modernbert.py:141-163,188-219  rotary tables and apply_rotary_pos_emb (fp32 rotate, half-split)
+//   TF:models/modernbert/modeling_modernbert.py:89-91             GeGLU with exact-erf GELU
+//   ref:cm3p/modeling_cm3p.py:385-396,631-642                     cls / masked-mean pooling
+#include "common.h"
+
+namespace {
+
+inline int ew_grid(int64_t items, int per_block = 256) {
+    int64_t blocks = (items + per_block - 1) / per_block;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 w, float (&f)[8]) {
+    f[0] = bf16lo(w.x); f[1] = bf16hi(w.x); f[2] = bf16lo(w.y); f[3] = bf16hi(w.y);
+    f[4] = bf16lo(w.z); f[5] = bf16hi(w.z); f[6] = bf16lo(w.w); f[7] = bf16hi(w.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return uint4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        reinterpret_cast<uint2*>(y)[i] = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    }
+}
+
+template <bool B_BF16>
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const void* __restrict__ b, float* y32,
+                                                      uint16_t* __restrict__ y16, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+        if constexpr (B_BF16) {
+            const uint2 w = reinterpret_cast<const uint2*>(b)[i];
+            v += f32x4{bf16lo(w.x), bf16hi(w.x), bf16lo(w.y), bf16hi(w.y)};
+        } else {
+            v += reinterpret_cast<const f32x4*>(b)[i];
+        }
+        if (y32) reinterpret_cast<f32x4*>(y32)[i] = v;
+        if (y16) reinterpret_cast<uint2*>(y16)[i] = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    }
+}
+
+// ---- RoPE ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restrict__ pos, const float* __restrict__ inv_freq,
+                                                         float* __restrict__ cos_out, float* __restrict__ sin_out, int64_t n,
+                                                         int half) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * half; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / half;
+        const int j = (int)(i % half);
+        const float ang = (float)pos[p] * inv_freq[j];  // one fp32 product, as the reference's (d/2,1)@(1,S) matmul
+        cos_out[i] = cosf(ang);
+        sin_out[i] = sinf(ang);
+    }
+}
+
+// One thread rotates 8 (j, j+32) pairs of one head: two 16-byte loads, two 16-byte stores.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void rope_apply_kernel(uint16_t* __restrict__ qkv, const float* __restrict__ cos_tab,
+                                                         const float* __restrict__ sin_tab, int64_t T, int S, int nh,
+                                                         int64_t pos_batch_stride) {
+    const int64_t per_tok = (int64_t)2 * nh * 4;
+    const int64_t total = T * per_tok;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / per_tok;
+        const int r = (int)(i % per_tok);
+        const int part = r / (nh * 4);  // 0 = q, 1 = k
+        const int h = (r / 4) % nh;
+        const int c = r & 3;
+        const int64_t b = t / S, s = t % S;
+        const int64_t prow = (pos_batch_stride ? b * pos_batch_stride : 0) + s;
+        uint16_t* base = qkv + (t * 3 + part) * (int64_t)nh * 64 + h * 64 + c * 8;
+        float x1[8], x2[8], cs[8], sn[8];
+        unpack8(*reinterpret_cast<const uint4*>(base), x1);
+        unpack8(*reinterpret_cast<const uint4*>(base + 32), x2);
+        const f32x4* cp = reinterpret_cast<const f32x4*>(cos_tab + prow * 32 + c * 8);
+        const f32x4* sp = reinterpret_cast<const f32x4*>(sin_tab + prow * 32 + c * 8);
+        const f32x4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        float y1[8], y2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (!INVERSE) {
+                y1[j] = x1[j] * cs[j] - x2[j] * sn[j];
+                y2[j] = x2[j] * cs[j] + x1[j] * sn[j];
+            } else {
+                y1[j] = x1[j] * cs[j] + x2[j] * sn[j];
+                y2[j] = x2[j] * cs[j] - x1[j] * sn[j];
+            }
+        }
+        *reinterpret_cast<uint4*>(base) = pack8(y1);
+        *reinterpret_cast<uint4*>(base + 32) = pack8(y2);
+    }
+}
+
+// ---- GeGLU / GELU -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ h, uint16_t* __restrict__ g, int64_t T, int I) {
+    const int c8 = I / 8;
+    const int64_t total = T * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / c8;
+        const int c = (int)(i % c8);
+        float a[8], b[8], y[8];
+        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + I + c * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = gelu_erf(a[j]) * b[j];
+        *reinterpret_cast<uint4*>(g + t * I + c * 8) = pack8(y);
+    }
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ dg, const uint16_t* __restrict__ h,
+                                                        uint16_t* __restrict__ dh, int64_t T, int I) {
+    const int c8 = I / 8;
+    const int64_t total = T * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / c8;
+        const int c = (int)(i % c8);
+        float a[8], b[8], d[8], da[8], db[8];
+        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + I + c * 8), b);
+        unpack8(*reinterpret_cast<const uint4*>(dg + t * I + c * 8), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            da[j] = d[j] * b[j] * gelu_erf_grad(a[j]);
+            db[j] = d[j] * gelu_erf(a[j]);
+        }
+        *reinterpret_cast<uint4*>(dh + t * 2 * I + c * 8) = pack8(da);
+        *reinterpret_cast<uint4*>(dh + t * 2 * I + I + c * 8) = pack8(db);
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float a[8], o[8];
+        unpack8(reinterpret_cast<const uint4*>(x)[i], a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = gelu_erf(a[j]);
+        reinterpret_cast<uint4*>(y)[i] = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                       uint16_t* __restrict__ dx, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float a[8], d[8], o[8];
+        unpack8(reinterpret_cast<const uint4*>(x)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(dy)[i], d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = d[j] * gelu_erf_grad(a[j]);
+        reinterpret_cast<uint4*>(dx)[i] = pack8(o);
+    }
+}
+
+// ---- pooling ------------------------------------------------------------------------------------------------
+constexpr int kPoolChunk = 128;
+
+// partial[b, c, :] = sum over the 128 rows of chunk c of h[b, s, :] * m[b, s]
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ h, const int64_t* __restrict__ mask,
+                                                           float* __restrict__ partial, int S, int H, int nchunks) {
+    const int b = blockIdx.x / nchunks, c = blockIdx.x % nchunks;
+    const int s0 = c * kPoolChunk, s1 = min(S, s0 + kPoolChunk);
+    for (int col = threadIdx.x * 4; col < H; col += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = s0; s < s1; ++s) {
+            const float m = mask ? (float)mask[(int64_t)b * S + s] : 1.0f;
+            acc += *reinterpret_cast<const f32x4*>(h + ((int64_t)b * S + s) * H + col) * m;
+        }
+        *reinterpret_cast<f32x4*>(partial + ((int64_t)b * nchunks + c) * H + col) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_final_kernel(const float* __restrict__ partial, const int64_t* __restrict__ mask,
+                                                         float* __restrict__ pooled, float* __restrict__ count, int S, int H,
+                                                         int nchunks) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float cnt = 0.f;
+    if (mask) {
+        for (int s = threadIdx.x; s < S; s += 256) cnt += (float)mask[(int64_t)b * S + s];
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        cnt = (red[0] + red[1]) + (red[2] + red[3]);
+    } else {
+        cnt = (float)S;
+    }
+    const float inv = 1.0f / fmaxf(cnt, 1e-9f);
+    if (threadIdx.x == 0 && count) count[b] = cnt;
+    for (int col = threadIdx.x; col < H; col += 256) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += partial[((int64_t)b * nchunks + c) * H + col];
+        pooled[(int64_t)b * H + col] = mask ? s * inv : s / (float)S;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_cls_kernel(const float* __restrict__ h, float* __restrict__ pooled, int S, int H) {
+    const int b = blockIdx.x;
+    for (int col = threadIdx.x; col < H; col += 256) pooled[(int64_t)b * H + col] = h[(int64_t)b * S * H + col];
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dpooled, const int64_t* __restrict__ mask,
+                                                       const float* __restrict__ count, float* __restrict__ dh, int Bn, int S,
+                                                       int H, int cls) {
+    const int h4 = H / 4;
+    const int64_t total = (int64_t)Bn * S * h4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / h4;
+        const int col = (int)(i % h4) * 4;
+        const int64_t b = row / S, s = row % S;
+        float scale;
+        if (cls) scale = (s == 0) ? 1.0f : 0.0f;
+        else if (mask) scale = (float)mask[row] / fmaxf(count[b], 1e-9f);
+        else scale = 1.0f / (float)S;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dpooled + b * H + col);
+        *reinterpret_cast<f32x4*>(dh + row * H + col) = g * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm3p_abi_version(void) { return CM3P_ABI_VERSION; }
+
+int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+    CM3P_REQUIRE(x && y && n >= 0 && n % 4 == 0);
+    if (n == 0) return CM3P_OK;
+    cast_f32_bf16_kernel<<<ew_grid(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(x, (uint16_t*)y, n / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_add_f32(const float* a, const void* b, int b_dtype, float* y_f32, void* y_bf16, int64_t n, void* stream) {
+    CM3P_REQUIRE(a && b && (y_f32 || y_bf16) && n >= 0 && n % 4 == 0);
+    if (n == 0) return CM3P_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (b_dtype == CM3P_BF16) add_f32_kernel<true><<<ew_grid(n / 4), 256, 0, s>>>(a, b, y_f32, (uint16_t*)y_bf16, n / 4);
+    else add_f32_kernel<false><<<ew_grid(n / 4), 256, 0, s>>>(a, b, y_f32, (uint16_t*)y_bf16, n / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_rope_table(const int64_t* position_ids, int64_t n_pos, const float* inv_freq, int half_dim, float* cos_out,
+                    float* sin_out, void* stream) {
+    CM3P_REQUIRE(position_ids && inv_freq && cos_out && sin_out && n_pos > 0 && half_dim > 0);
+    rope_table_kernel<<<ew_grid(n_pos * half_dim), 256, 0, static_cast<hipStream_t>(stream)>>>(position_ids, inv_freq, cos_out,
+                                                                                              sin_out, n_pos, half_dim);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B, int S, int nh, int64_t pos_batch_stride,
+                    int inverse, void* stream) {
+    CM3P_REQUIRE(qkv && cos_tab && sin_tab && B > 0 && S > 0 && nh > 0);
+    CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
+    const int64_t T = (int64_t)B * S;
+    const int grid = ew_grid(T * 2 * nh * 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (inverse) rope_apply_kernel<true><<<grid, 256, 0, s>>>((uint16_t*)qkv, cos_tab, sin_tab, T, S, nh, pos_batch_stride);
+    else rope_apply_kernel<false><<<grid, 256, 0, s>>>((uint16_t*)qkv, cos_tab, sin_tab, T, S, nh, pos_batch_stride);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_geglu_fwd(const void* h, void* g, int64_t T, int I, void* stream) {
+    CM3P_REQUIRE(h && g && T >= 0 && I > 0 && I % 8 == 0);
+    if (T == 0) return CM3P_OK;
+    geglu_fwd_kernel<<<ew_grid(T * (I / 8)), 256, 0, static_cast<hipStream_t>(stream)>>>((const uint16_t*)h, (uint16_t*)g, T, I);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_geglu_bwd(const void* dg, const void* h, void* dh, int64_t T, int I, void* stream) {
+    CM3P_REQUIRE(dg && h && dh && T >= 0 && I > 0 && I % 8 == 0);
+    if (T == 0) return CM3P_OK;
+    geglu_bwd_kernel<<<ew_grid(T * (I / 8)), 256, 0, static_cast<hipStream_t>(stream)>>>((const uint16_t*)dg, (const uint16_t*)h,
+                                                                                        (uint16_t*)dh, T, I);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+    CM3P_REQUIRE(x && y && n >= 0 && n % 8 == 0);
+    if (n == 0) return CM3P_OK;
+    gelu_fwd_kernel<<<ew_grid(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>((const uint16_t*)x, (uint16_t*)y, n / 8);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+    CM3P_REQUIRE(dy && x && dx && n >= 0 && n % 8 == 0);
+    if (n == 0) return CM3P_OK;
+    gelu_bwd_kernel<<<ew_grid(n / 8), 256, 0, static_cast<hipStream_t>(stream)>>>((const uint16_t*)dy, (const uint16_t*)x,
+                                                                                 (uint16_t*)dx, n / 8);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_pool_chunks(int S) { return (S + kPoolChunk - 1) / kPoolChunk; }
+
+int cm3p_pool_fwd(const float* h, const int64_t* mask, float* pooled, float* partial, float* count, int Bn, int S, int H,
+                  int cls, void* stream) {
+    CM3P_REQUIRE(h && pooled && Bn > 0 && S > 0 && H > 0 && H % 4 == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cls) {
+        pool_cls_kernel<<<Bn, 256, 0, s>>>(h, pooled, S, H);
+    } else {
+        CM3P_REQUIRE(partial);
+        const int nch = cm3p_pool_chunks(S);
+        pool_partial_kernel<<<Bn * nch, 256, 0, s>>>(h, mask, partial, S, H, nch);
+        CM3P_LAUNCH_CHECK();
+        pool_final_kernel<<<Bn, 256, 0, s>>>(partial, mask, pooled, count, S, H, nch);
+    }
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_pool_bwd(const float* dpooled, const int64_t* mask, const float* count, float* dh, int Bn, int S, int H, int cls,
+                  void* stream) {
+    CM3P_REQUIRE(dpooled && dh && Bn > 0 && S > 0 && H > 0 && H % 4 == 0);
+    CM3P_REQUIRE(cls || !mask || count);
+    pool_bwd_kernel<<<ew_grid((int64_t)Bn * S * (H / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(dpooled, mask, count, dh,
+                                                                                                      Bn, S, H, cls);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// Contrastive head in fp32: projections, L2 normalisation, scaled similarity logits and the symmetric cross-entropy
+// (ref:cm3p/modeling_cm3p.py:27-62, 958-985).  The problems are tiny (batch x 512 x 768); the kernels favour fixed
+// summation order (bitwise reproducible) over throughput.
+#include "common.h"
+
+namespace {
+
+// C[m, n] (+)= alpha * sum_k A[m*a_rs + k*a_cs] * B[n*b_rs + k*b_cs];  16 x 16 outputs per block, k tiled by 16 via LDS
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, int M, int N, int K, int64_t a_rs, int64_t a_cs,
+                                                       int64_t b_rs, int64_t b_cs, int64_t ldc, float alpha, int accumulate) {
+    __shared__ float sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // thread (ty, tx) loads A[m0+ty][k0+tx] and B[n0+ty][k0+tx]
+        const int k = k0 + tx;
+        sa[ty][tx] = (m0 + ty < M && k < K) ? A[(int64_t)(m0 + ty) * a_rs + (int64_t)k * a_cs] : 0.f;
+        sb[ty][tx] = (n0 + ty < N && k < K) ? B[(int64_t)(n0 + ty) * b_rs + (int64_t)k * b_cs] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = fmaf(sa[ty][kk], sb[tx][kk], acc);
+        __syncthreads();
+    }
+    const int m = m0 + ty, n = n0 + tx;
+    if (m < M && n < N) {
+        float* c = C + (int64_t)m * ldc + n;
+        *c = accumulate ? *c + alpha * acc : alpha * acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ norm, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = x[(int64_t)row * D + c];
+        s += v * v;
+    }
+    const float nrm = sqrtf(wave_sum(s));
+    for (int c = lane; c < D; c += 64) y[(int64_t)row * D + c] = x[(int64_t)row * D + c] / nrm;
+    if (lane == 0) norm[row] = nrm;
+}
+
+// y = x / n  ->  dx = (dy - y * <y, dy>) / n
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ norm, float* __restrict__ dx, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += y[(int64_t)row * D + c] * dy[(int64_t)row * D + c];
+    s = wave_sum(s);
+    const float inv = 1.0f / norm[row];
+    for (int c = lane; c < D; c += 64) dx[(int64_t)row * D + c] = (dy[(int64_t)row * D + c] - y[(int64_t)row * D + c] * s) * inv;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int cols, int64_t row_stride,
+                                                            int64_t col_stride, const int64_t* __restrict__ row_offset,
+                                                            const int64_t* __restrict__ target, float grad_scale,
+                                                            float* __restrict__ loss_rows, float* dlogits) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int64_t base = row_offset ? row_offset[r] : (int64_t)r * row_stride;
+    const float* x = logits + base;
+    float mx = -__builtin_huge_valf();
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, x[(int64_t)c * col_stride]);
+    mx = block_reduce(mx, red, true);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) se += expf(x[(int64_t)c * col_stride] - mx);
+    se = block_reduce(se, red, false);
+    const float lse = mx + logf(se);
+    const int64_t t = target[r];
+    if (threadIdx.x == 0) loss_rows[r] = lse - x[t * col_stride];
+    if (dlogits) {
+        float* d = dlogits + base;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float p = expf(x[(int64_t)c * col_stride] - lse);
+            d[(int64_t)c * col_stride] += grad_scale * (p - (c == t ? 1.0f : 0.0f));
+        }
+    }
+}
+
+__global__ void first_zero_index_kernel(const int64_t* __restrict__ classes, int B, int V, int64_t* __restrict__ idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t r = 0;
+    for (int v = 0; v < V; ++v)
+        if (classes[(int64_t)b * V + v] == 0) {
+            r = v;
+            break;
+        }
+    idx[b] = r;
+}
+
+// y[i] = x[i] * exp(*log_scale)
+__global__ __launch_bounds__(256) void scale_exp_kernel(const float* __restrict__ x, const float* __restrict__ log_scale,
+                                                        float* __restrict__ y, int64_t n) {
+    const float s = expf(*log_scale);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * s;
+}
+
+// out[0] = sum_i a[i] * b[i], single block, fixed order
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                  int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += a[i] * b[i];
+    s = block_reduce(s, red, false);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// out[0] = scale * sum_i x[i]
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale,
+                                                  int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_reduce(s, red, false);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + scale * s : scale * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm3p_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_rs, int64_t a_cs, int64_t b_rs,
+                  int64_t b_cs, int64_t ldc, float alpha, int accumulate, void* stream) {
+    CM3P_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N);
+    const dim3 grid((N + 15) / 16, (M + 15) / 16);
+    gemm_f32_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, ldc, alpha, accumulate);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_l2norm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream) {
+    CM3P_REQUIRE(x && y && norm && rows > 0 && D > 0);
+    l2norm_fwd_kernel<<<(rows + 3) / 4, 256, 0, static_cast<hipStream_t>(stream)>>>(x, y, norm, rows, D);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream) {
+    CM3P_REQUIRE(dy && y && norm && dx && rows > 0 && D > 0);
+    l2norm_bwd_kernel<<<(rows + 3) / 4, 256, 0, static_cast<hipStream_t>(stream)>>>(dy, y, norm, dx, rows, D);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_cross_entropy(const float* logits, int rows, int cols, int64_t row_stride, int64_t col_stride,
+                       const int64_t* row_offset, const int64_t* target, float grad_scale, float* loss_rows, float* dlogits,
+                       void* stream) {
+    CM3P_REQUIRE(logits && target && loss_rows && rows > 0 && cols > 0);
+    cross_entropy_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(logits, cols, row_stride, col_stride, row_offset,
+                                                                            target, grad_scale, loss_rows, dlogits);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream) {
+    CM3P_REQUIRE(classes && idx && B > 0 && V > 0);
+    first_zero_index_kernel<<<(B + 63) / 64, 64, 0, static_cast<hipStream_t>(stream)>>>(classes, B, V, idx);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_scale_exp(const float* x, const float* log_scale, float* y, int64_t n, void* stream) {
+    CM3P_REQUIRE(x && log_scale && y && n > 0);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    scale_exp_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, log_scale, y, n);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    CM3P_REQUIRE(a && b && out && n > 0);
+    dot_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(a, b, out, n);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_sum_f32(const float* x, float* out, int64_t n, float scale, int accumulate, void* stream) {
+    CM3P_REQUIRE(x && out && n > 0);
+    sum_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(x, out, n, scale, accumulate);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+}  // extern "C"

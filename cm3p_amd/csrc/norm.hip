@@ -1,0 +1,410 @@
+// Bias-free LayerNorm (forward / backward), the fused token-embedding gather + LayerNorm, and the small
+// reductions that go with them.  All of it is HBM-bound: one wave owns a row, 16-byte accesses, fp32 statistics.
+//
+// Math restated from the reference's encoder (third-party, not vendored):
+//   TF:models/modernbert/modeling_modernbert.py:61,64-71   embeddings: LayerNorm(tok_embeddings(ids)), no bias
+//   TF:models/modernbert/modeling_modernbert.py:309-314,420 attn_norm / mlp_norm / final_norm = nn.LayerNorm(H, eps, bias=False)
+//   ref:cm3p/modeling_cm3p.py:592,603-605                   embedding lookup and the audio-embedding scatter
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxChunks = 8;  // 8 * 64 lanes * 4 floats = H <= 2048
+
+struct RowRegs {
+    f32x4 v[kMaxChunks];
+};
+
+// load a row of H values (fp32 or bf16 source) into registers, lane owns columns c*256 + lane*4 .. +3
+template <bool SRC_BF16>
+__device__ __forceinline__ void load_row(RowRegs& r, const void* src, int H, int lane) {
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) {
+            if constexpr (SRC_BF16) {
+                const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(src) + col);
+                r.v[c] = f32x4{bf16lo(w.x), bf16hi(w.x), bf16lo(w.y), bf16hi(w.y)};
+            } else {
+                r.v[c] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + col);
+            }
+        } else {
+            r.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+__device__ __forceinline__ void row_stats(const RowRegs& r, int H, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) s += (r.v[c].x + r.v[c].y) + (r.v[c].z + r.v[c].w);
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) {
+            const f32x4 d = r.v[c] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+    const float var = wave_sum(q) / (float)H;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ void store_norm(const RowRegs& r, const float* __restrict__ w, float mean, float rstd,
+                                           float* y32, uint16_t* y16, int H, int lane) {
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(w + col);
+            const f32x4 y = (r.v[c] - mean) * rstd * g;
+            if (y32) *reinterpret_cast<f32x4*>(y32 + col) = y;
+            if (y16) *reinterpret_cast<uint2*>(y16 + col) = uint2{pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+        }
+    }
+}
+
+template <bool X_BF16>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y32, uint16_t* __restrict__ y16,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        RowRegs r;
+        const void* src = X_BF16 ? (const void*)(static_cast<const uint16_t*>(x) + row * H)
+                                 : (const void*)(static_cast<const float*>(x) + row * H);
+        load_row<X_BF16>(r, src, H, lane);
+        float mean, rstd;
+        row_stats(r, H, lane, eps, mean, rstd);
+        store_norm(r, w, mean, rstd, y32 ? y32 + row * H : nullptr, y16 ? y16 + row * H : nullptr, H, lane);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+// Backward.  xhat = (x - mean) * rstd, g = dy * w:
+//   dx = rstd * (g - mean_H(g) - xhat * mean_H(g * xhat)) [+ dres]      dw[col] = sum_rows dy * xhat
+// Each wave walks rows grid-stride and keeps its dw partial in registers; one partial row per block.
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, const float* dres,
+                                                            float* dx32, uint16_t* __restrict__ dx16,
+                                                            float* __restrict__ dw_partial, int64_t rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];  // [4][H]
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    RowRegs dw;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        RowRegs xr, gr;
+        load_row<false>(xr, x + row * H, H, lane);
+        const void* dsrc = DY_BF16 ? (const void*)(static_cast<const uint16_t*>(dy) + row * H)
+                                   : (const void*)(static_cast<const float*>(dy) + row * H);
+        load_row<DY_BF16>(gr, dsrc, H, lane);
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const f32x4 xhat = (xr.v[c] - mean) * rstd;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + col);
+                dw.v[c] += gr.v[c] * xhat;
+                const f32x4 g = gr.v[c] * wv;
+                xr.v[c] = xhat;
+                gr.v[c] = g;
+                s1 += (g.x + g.y) + (g.z + g.w);
+                const f32x4 gx = g * xhat;
+                s2 += (gx.x + gx.y) + (gx.z + gx.w);
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
+                if (dres) d += *reinterpret_cast<const f32x4*>(dres + row * H + col);
+                if (dx32) *reinterpret_cast<f32x4*>(dx32 + row * H + col) = d;
+                if (dx16) *reinterpret_cast<uint2*>(dx16 + row * H + col) = uint2{pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w)};
+            }
+        }
+    }
+    // block-level reduction of the four waves' dw partials, fixed order -> deterministic
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) *reinterpret_cast<f32x4*>(dw_lds + wid * H + col) = dw.v[c];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+        dw_partial[(int64_t)blockIdx.x * H + col] = (dw_lds[col] + dw_lds[H + col]) + (dw_lds[2 * H + col] + dw_lds[3 * H + col]);
+    }
+}
+
+// out[col] = sum_b partial[b][col], fixed summation order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * H + col];
+    out[col] = s;
+}
+
+// ---- embedding gather + LayerNorm ---------------------------------------------------------------------------
+// Source row of token t: override_rows[slot[t]] when slot && slot[t] >= 0 (audio placeholder,
+// ref:cm3p/modeling_cm3p.py:603-605), else table[ids[t]].
+template <bool TAB_BF16, bool OVR_BF16>
+__device__ __forceinline__ void load_embed_row(RowRegs& r, const int64_t* ids, const void* table, const int32_t* slot,
+                                               const void* ovr, int64_t t, int H, int lane) {
+    const int s = slot ? slot[t] : -1;
+    if (s >= 0) {
+        const void* src = OVR_BF16 ? (const void*)(static_cast<const uint16_t*>(ovr) + (int64_t)s * H)
+                                   : (const void*)(static_cast<const float*>(ovr) + (int64_t)s * H);
+        load_row<OVR_BF16>(r, src, H, lane);
+    } else {
+        const int64_t id = ids[t];
+        const void* src = TAB_BF16 ? (const void*)(static_cast<const uint16_t*>(table) + id * H)
+                                   : (const void*)(static_cast<const float*>(table) + id * H);
+        load_row<TAB_BF16>(r, src, H, lane);
+    }
+}
+
+template <bool TAB_BF16, bool OVR_BF16>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const void* __restrict__ table,
+                                                           const int32_t* __restrict__ slot, const void* __restrict__ ovr,
+                                                           const float* __restrict__ w, float* __restrict__ y32,
+                                                           uint16_t* __restrict__ y16, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, int64_t T, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t t = wave; t < T; t += nwaves) {
+        RowRegs r;
+        load_embed_row<TAB_BF16, OVR_BF16>(r, ids, table, slot, ovr, t, H, lane);
+        float mean, rstd;
+        row_stats(r, H, lane, eps, mean, rstd);
+        store_norm(r, w, mean, rstd, y32 ? y32 + t * H : nullptr, y16 ? y16 + t * H : nullptr, H, lane);
+        if (lane == 0) {
+            mean_out[t] = mean;
+            rstd_out[t] = rstd;
+        }
+    }
+}
+
+// Backward of the gather + LayerNorm: LayerNorm backward on the re-gathered row, then the row gradient is
+// scattered: atomically added into d_table[ids[t]] (several tokens share a row) or stored to d_override[slot[t]]
+// (each audio row is used exactly once).
+template <bool TAB_BF16, bool OVR_BF16>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                           const void* __restrict__ table, const int32_t* __restrict__ slot,
+                                                           const void* __restrict__ ovr, const float* __restrict__ w,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           float* __restrict__ d_table, float* __restrict__ d_ovr,
+                                                           float* __restrict__ dw_partial, int64_t T, int H,
+                                                           int64_t padding_idx) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    RowRegs dw;
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = wave; t < T; t += nwaves) {
+        RowRegs xr, gr;
+        load_embed_row<TAB_BF16, OVR_BF16>(xr, ids, table, slot, ovr, t, H, lane);
+        load_row<false>(gr, dy + t * H, H, lane);
+        const float mean = mean_in[t], rstd = rstd_in[t];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const f32x4 xhat = (xr.v[c] - mean) * rstd;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + col);
+                dw.v[c] += gr.v[c] * xhat;
+                const f32x4 g = gr.v[c] * wv;
+                xr.v[c] = xhat;
+                gr.v[c] = g;
+                s1 += (g.x + g.y) + (g.z + g.w);
+                const f32x4 gx = g * xhat;
+                s2 += (gx.x + gx.y) + (gx.z + gx.w);
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        const int s = slot ? slot[t] : -1;
+        // nn.Embedding(padding_idx=pad_token_id) gives the padding row no gradient (TF:...modeling_modernbert.py:60)
+        const int64_t id = ids[t];
+        float* dst = s >= 0 ? (d_ovr ? d_ovr + (int64_t)s * H : nullptr)
+                            : ((d_table && id != padding_idx) ? d_table + id * H : nullptr);
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H && dst) {
+                const f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
+                if (s >= 0) {
+                    *reinterpret_cast<f32x4*>(dst + col) = d;
+                } else {
+                    atomicAdd(dst + col + 0, d.x);
+                    atomicAdd(dst + col + 1, d.y);
+                    atomicAdd(dst + col + 2, d.z);
+                    atomicAdd(dst + col + 3, d.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) *reinterpret_cast<f32x4*>(dw_lds + wid * H + col) = dw.v[c];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+        dw_partial[(int64_t)blockIdx.x * H + col] = (dw_lds[col] + dw_lds[H + col]) + (dw_lds[2 * H + col] + dw_lds[3 * H + col]);
+    }
+}
+
+// slot[t] = (ids[t] == audio_id) ? number of audio placeholders before t in row-major (b, s) order : -1.
+// Single-block exclusive scan (T is at most a few hundred thousand); count[0] = total placeholders.
+__global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __restrict__ ids, int64_t T, int64_t audio_id,
+                                                           int32_t* __restrict__ slot, int32_t* __restrict__ count) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < T; base += 1024) {
+        const int64_t t = base + threadIdx.x;
+        const int flag = (t < T && ids[t] == audio_id) ? 1 : 0;
+        const unsigned long long ball = __ballot(flag);
+        const int before = __popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wid] = __popcll(ball);
+        __syncthreads();
+        int off = carry;
+        for (int i = 0; i < wid; ++i) off += wave_tot[i];
+        if (t < T) slot[t] = flag ? off + before : -1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int i = 0; i < 16; ++i) tot += wave_tot[i];
+            carry += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = carry;
+}
+
+inline int ln_grid(int64_t rows) {
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm3p_layernorm_fwd(const void* x, int x_dtype, const float* weight, float* y_f32, void* y_bf16, float* mean, float* rstd,
+                       int64_t rows, int H, float eps, void* stream) {
+    CM3P_REQUIRE(x && weight && (y_f32 || y_bf16) && rows >= 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    CM3P_REQUIRE(x_dtype == CM3P_F32 || x_dtype == CM3P_BF16);
+    if (rows == 0) return CM3P_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_dtype == CM3P_BF16)
+        layernorm_fwd_kernel<true><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
+    else
+        layernorm_fwd_kernel<false><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_layernorm_bwd_blocks(int64_t rows) { return ln_grid(rows); }
+
+int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* weight, const float* mean, const float* rstd,
+                       const float* dres, float* dx_f32, void* dx_bf16, float* dw_partial, float* dw, int64_t rows, int H,
+                       void* stream) {
+    CM3P_REQUIRE(dy && x && weight && mean && rstd && dw_partial && dw && (dx_f32 || dx_bf16));
+    CM3P_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    CM3P_REQUIRE(dy_dtype == CM3P_F32 || dy_dtype == CM3P_BF16);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = ln_grid(rows);
+    const size_t lds = (size_t)4 * H * sizeof(float);
+    if (dy_dtype == CM3P_BF16)
+        layernorm_bwd_kernel<true><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
+    else
+        layernorm_bwd_kernel<false><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
+    CM3P_LAUNCH_CHECK();
+    colsum_kernel<<<(H + 255) / 256, 256, 0, s>>>(dw_partial, dw, grid, H);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, const int32_t* slot, const void* override_rows,
+                      int override_dtype, const float* weight, float* y_f32, void* y_bf16, float* mean, float* rstd, int64_t T,
+                      int H, float eps, void* stream) {
+    CM3P_REQUIRE(ids && table && weight && mean && rstd && (y_f32 || y_bf16) && T >= 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
+    if (T == 0) return CM3P_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = ln_grid(T);
+    const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
+#define CM3P_EMB_FWD(TB, OB)                                                                                           \
+    embed_ln_fwd_kernel<TB, OB><<<grid, 256, 0, s>>>(ids, table, slot, override_rows, weight, y_f32, (uint16_t*)y_bf16, \
+                                                     mean, rstd, T, H, eps)
+    if (tb && ob) CM3P_EMB_FWD(true, true);
+    else if (tb) CM3P_EMB_FWD(true, false);
+    else if (ob) CM3P_EMB_FWD(false, true);
+    else CM3P_EMB_FWD(false, false);
+#undef CM3P_EMB_FWD
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
+                      const void* override_rows, int override_dtype, const float* weight, const float* mean, const float* rstd,
+                      float* d_table, float* d_override, float* dw_partial, float* dw, int64_t T, int H, int64_t padding_idx,
+                      void* stream) {
+    CM3P_REQUIRE(dy && ids && table && weight && mean && rstd && dw_partial && dw && T > 0 && H > 0 && H % 4 == 0 && H <= 2048);
+    CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = ln_grid(T);
+    const size_t lds = (size_t)4 * H * sizeof(float);
+    const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
+#define CM3P_EMB_BWD(TB, OB)                                                                                          \
+    embed_ln_bwd_kernel<TB, OB><<<grid, 256, lds, s>>>(dy, ids, table, slot, override_rows, weight, mean, rstd, d_table, \
+                                                       d_override, dw_partial, T, H, padding_idx)
+    if (tb && ob) CM3P_EMB_BWD(true, true);
+    else if (tb) CM3P_EMB_BWD(true, false);
+    else if (ob) CM3P_EMB_BWD(false, true);
+    else CM3P_EMB_BWD(false, false);
+#undef CM3P_EMB_BWD
+    CM3P_LAUNCH_CHECK();
+    colsum_kernel<<<(H + 255) / 256, 256, 0, s>>>(dw_partial, dw, grid, H);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int32_t* slot, int32_t* count, void* stream) {
+    CM3P_REQUIRE(ids && slot && count && T > 0);
+    audio_slots_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(ids, T, audio_token_id, slot, count);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""Typed Python wrappers over the C ABI: allocate outputs (torch = device memory only), launch, return tensors.
+
+No autograd here and no torch compute ops: everything numerical happens inside libcm3p_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_BF16, EPI_F32, EPI_F32_RESID, F32, call, dt, ptr, query, stream
+
+Tensor = torch.Tensor
+
+
+def _empty(shape, dtype, like: Tensor) -> Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x: Tensor, weight: Tensor, eps: float, want_f32: bool, want_bf16: bool, want_stats: bool = True):
+    """x [rows, H] fp32|bf16 -> (y_f32|None, y_bf16|None, mean|None, rstd|None)."""
+    rows, H = x.shape
+    y32 = _empty((rows, H), torch.float32, x) if want_f32 else None
+    y16 = _empty((rows, H), torch.bfloat16, x) if want_bf16 else None
+    mean = _empty((rows,), torch.float32, x) if want_stats else None
+    rstd = _empty((rows,), torch.float32, x) if want_stats else None
+    call("cm3p_layernorm_fwd", ptr(x), dt(x), ptr(weight), ptr(y32), ptr(y16), ptr(mean), ptr(rstd), rows, H, eps, stream())
+    return y32, y16, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, weight: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor],
+                  want_bf16: bool, inplace: bool = True):
+    """-> (dx_f32 = dres + LN'(dy), dx_bf16|None, dw[H]).  With `inplace` dx_f32 overwrites dres."""
+    rows, H = x.shape
+    dx32 = dres if (inplace and dres is not None) else _empty((rows, H), torch.float32, x)
+    dx16 = _empty((rows, H), torch.bfloat16, x) if want_bf16 else None
+    nblk = query("cm3p_layernorm_bwd_blocks", rows)
+    part = _empty((nblk, H), torch.float32, x)
+    dw = _empty((H,), torch.float32, x)
+    call("cm3p_layernorm_bwd", ptr(dy), dt(dy), ptr(x), ptr(weight), ptr(mean), ptr(rstd), ptr(dres), ptr(dx32), ptr(dx16),
+         ptr(part), ptr(dw), rows, H, stream())
+    return dx32, dx16, dw
+
+
+def embed_ln_fwd(ids: Tensor, table: Tensor, weight: Tensor, eps: float, slot: Optional[Tensor] = None,
+                 override: Optional[Tensor] = None, want_bf16: bool = False):
+    T = ids.numel()
+    H = table.shape[1]
+    y32 = _empty((T, H), torch.float32, table)
+    y16 = _empty((T, H), torch.bfloat16, table) if want_bf16 else None
+    mean = _empty((T,), torch.float32, table)
+    rstd = _empty((T,), torch.float32, table)
+    call("cm3p_embed_ln_fwd", ptr(ids), ptr(table), dt(table), ptr(slot), ptr(override), dt(override) if override is not None else F32,
+         ptr(weight), ptr(y32), ptr(y16), ptr(mean), ptr(rstd), T, H, eps, stream())
+    return y32, y16, mean, rstd
+
+
+def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: Tensor, rstd: Tensor, padding_idx: int,
+                 slot: Optional[Tensor] = None, override: Optional[Tensor] = None, want_table_grad: bool = True):
+    T = ids.numel()
+    V, H = table.shape
+    d_table = torch.zeros((V, H), dtype=torch.float32, device=table.device) if want_table_grad else None
+    d_ovr = _empty(override.shape, torch.float32, table) if override is not None else None
+    nblk = query("cm3p_layernorm_bwd_blocks", T)
+    part = _empty((nblk, H), torch.float32, table)
+    dw = _empty((H,), torch.float32, table)
+    call("cm3p_embed_ln_bwd", ptr(dy), ptr(ids), ptr(table), dt(table), ptr(slot), ptr(override),
+         dt(override) if override is not None else F32, ptr(weight), ptr(mean), ptr(rstd), ptr(d_table), ptr(d_ovr), ptr(part), ptr(dw),
+         T, H, padding_idx, stream())
+    return d_table, d_ovr, dw
+
+
+def audio_slots(ids: Tensor, audio_token_id: int):
+    T = ids.numel()
+    slot = torch.empty((T,), dtype=torch.int32, device=ids.device)
+    count = torch.empty((1,), dtype=torch.int32, device=ids.device)
+    call("cm3p_audio_slots", ptr(ids), T, audio_token_id, ptr(slot), ptr(count), stream())
+    return slot, count
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _wgrad_splits(M: int, N: int, K: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 512 or K <= 1024:
+        return 1
+    return max(1, min((1024 + tiles - 1) // tiles, K // 512))
+
+
+def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, epilogue: int,
+         resid: Optional[Tensor] = None, out: Optional[Tensor] = None, split_k: int = 1) -> Tensor:
+    """C[m,n] = sum_k A(m,k) B(n,k) (+resid).  a/b bf16, row-major 2-D; see include/cm3p_hip.h for the layouts."""
+    lda, ldb = a.shape[1], b.shape[1]
+    if out is None:
+        out = _empty((M, N), torch.bfloat16 if epilogue == EPI_BF16 else torch.float32, a)
+    ws = _empty((split_k, M, N), torch.float32, a) if split_k > 1 else None
+    call("cm3p_gemm_bf16", ptr(a), ptr(b), ptr(out), ptr(resid), M, N, K, lda, ldb, N, int(a_kc), int(b_kc), epilogue, split_k,
+         ptr(ws), stream())
+    return out
+
+
+def linear_fwd(x: Tensor, w: Tensor, resid: Optional[Tensor] = None) -> Tensor:
+    """x [T,K] bf16, w [N,K] bf16 -> x w^T as bf16, or fp32 resid + x w^T."""
+    T, K = x.shape
+    N = w.shape[0]
+    return gemm(x, w, T, N, K, True, True, EPI_F32_RESID if resid is not None else EPI_BF16, resid)
+
+
+def linear_dgrad(dy: Tensor, w: Tensor) -> Tensor:
+    """dy [T,N] bf16, w [N,K] bf16 -> dx [T,K] bf16 = dy w."""
+    T, N = dy.shape
+    K = w.shape[1]
+    return gemm(dy, w, T, K, N, True, False, EPI_BF16)
+
+
+def linear_wgrad(dy: Tensor, x: Tensor) -> Tensor:
+    """dy [T,N] bf16, x [T,K] bf16 -> dW [N,K] fp32 = dy^T x (split-K over tokens, deterministic combine)."""
+    T, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, N, K, T, False, False, EPI_F32, split_k=_wgrad_splits(N, K, T))
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("cm3p_cast_f32_bf16", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def add_f32(a: Tensor, b: Tensor, want_bf16: bool = False, inplace: bool = True):
+    y32 = a if inplace else torch.empty_like(a)
+    y16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    call("cm3p_add_f32", ptr(a), ptr(b), dt(b), ptr(y32), ptr(y16), a.numel(), stream())
+    return y32, y16
+
+
+# ------------------------------------------------------------------------------------------------ RoPE / attention
+def rope_table(position_ids: Tensor, inv_freq: Tensor):
+    n = position_ids.numel()
+    half = inv_freq.numel()
+    cos = torch.empty((n, half), dtype=torch.float32, device=inv_freq.device)
+    sin = torch.empty((n, half), dtype=torch.float32, device=inv_freq.device)
+    call("cm3p_rope_table", ptr(position_ids), n, ptr(inv_freq), half, ptr(cos), ptr(sin), stream())
+    return cos, sin
+
+
+def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, per_batch: bool, inverse: bool = False):
+    call("cm3p_rope_apply", ptr(qkv), ptr(cos), ptr(sin), B, S, nh, S if per_batch else 0, int(inverse), stream())
+    return qkv
+
+
+def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float):
+    out = torch.empty((B * S, nh * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
+    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(key_mask), B, S, nh, window, scale, stream())
+    return out, lse
+
+
+def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
+             window: int, scale: float) -> Tensor:
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(key_mask), B, S, nh, window, scale,
+         stream())
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------ MLP pieces
+def geglu_fwd(h: Tensor) -> Tensor:
+    T, I2 = h.shape
+    g = torch.empty((T, I2 // 2), dtype=torch.bfloat16, device=h.device)
+    call("cm3p_geglu_fwd", ptr(h), ptr(g), T, I2 // 2, stream())
+    return g
+
+
+def geglu_bwd(dg: Tensor, h: Tensor) -> Tensor:
+    dh = torch.empty_like(h)
+    call("cm3p_geglu_bwd", ptr(dg), ptr(h), ptr(dh), h.shape[0], h.shape[1] // 2, stream())
+    return dh
+
+
+def gelu_fwd(x: Tensor) -> Tensor:
+    y = torch.empty_like(x)
+    call("cm3p_gelu_fwd", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
+    dx = torch.empty_like(x)
+    call("cm3p_gelu_bwd", ptr(dy), ptr(x), ptr(dx), x.numel(), stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+def pool_fwd(h: Tensor, mask: Optional[Tensor], Bn: int, S: int, cls: bool):
+    H = h.shape[-1]
+    pooled = torch.empty((Bn, H), dtype=torch.float32, device=h.device)
+    count = torch.empty((Bn,), dtype=torch.float32, device=h.device)
+    part = None if cls else torch.empty((Bn, query("cm3p_pool_chunks", S), H), dtype=torch.float32, device=h.device)
+    call("cm3p_pool_fwd", ptr(h), ptr(mask), ptr(pooled), ptr(part), ptr(count), Bn, S, H, int(cls), stream())
+    return pooled, count
+
+
+def pool_bwd(dpooled: Tensor, mask: Optional[Tensor], count: Tensor, Bn: int, S: int, cls: bool) -> Tensor:
+    H = dpooled.shape[-1]
+    dh = torch.empty((Bn * S, H), dtype=torch.float32, device=dpooled.device)
+    call("cm3p_pool_bwd", ptr(dpooled), ptr(mask), ptr(count), ptr(dh), Bn, S, H, int(cls), stream())
+    return dh
+
+
+# ------------------------------------------------------------------------------------------------ fp32 head
+def gemm_f32(a: Tensor, b: Tensor, M: int, N: int, K: int, a_strides, b_strides, alpha: float = 1.0,
+             out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    call("cm3p_gemm_f32", ptr(a), ptr(b), ptr(out), M, N, K, a_strides[0], a_strides[1], b_strides[0], b_strides[1], N, alpha,
+         int(accumulate), stream())
+    return out
+
+
+def l2norm_fwd(x: Tensor):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    norm = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    call("cm3p_l2norm_fwd", ptr(x), ptr(y), ptr(norm), rows, D, stream())
+    return y, norm
+
+
+def l2norm_bwd(dy: Tensor, y: Tensor, norm: Tensor) -> Tensor:
+    dx = torch.empty_like(y)
+    call("cm3p_l2norm_bwd", ptr(dy), ptr(y), ptr(norm), ptr(dx), y.shape[0], y.shape[1], stream())
+    return dx
+
+
+def cross_entropy(logits: Tensor, rows: int, cols: int, row_stride: int, col_stride: int, target: Tensor,
+                  row_offset: Optional[Tensor], grad_scale: float, dlogits: Optional[Tensor]) -> Tensor:
+    loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    call("cm3p_cross_entropy", ptr(logits), rows, cols, row_stride, col_stride, ptr(row_offset), ptr(target), grad_scale,
+         ptr(loss_rows), ptr(dlogits), stream())
+    return loss_rows
+
+
+def first_zero_index(classes: Tensor) -> Tensor:
+    B, V = classes.shape
+    idx = torch.empty((B,), dtype=torch.int64, device=classes.device)
+    call("cm3p_first_zero_index", ptr(classes), B, V, ptr(idx), stream())
+    return idx
+
+
+def scale_exp(x: Tensor, log_scale: Tensor) -> Tensor:
+    y = torch.empty_like(x)
+    call("cm3p_scale_exp", ptr(x), ptr(log_scale), ptr(y), x.numel(), stream())
+    return y
+
+
+def dot_f32(a: Tensor, b: Tensor) -> Tensor:
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    call("cm3p_dot_f32", ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    return out
+
+
+def sum_f32(x: Tensor, scale: float, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    call("cm3p_sum_f32", ptr(x), ptr(out), x.numel(), scale, int(accumulate), stream())
+    return out

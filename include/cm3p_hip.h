@@ -1,0 +1,183 @@
+/*
+ * cm3p_hip.h - C ABI of libcm3p_hip.so: the MI355X (gfx950) kernels behind CM3P's contrastive training hot path.
+ *
+ * The reference (OliBomby/CM3P) is pure Python: it has no FFI, and its hot path runs inside PyTorch ops called from
+ * ref:cm3p/modeling_cm3p.py and the third-party encoder TF:models/modernbert/modeling_modernbert.py (TF: = the
+ * `transformers` package the reference depends on).  Each entry point below therefore names the reference Python
+ * call it replaces.  The Python binding that a maintainer adds is `cm3p_amd/_lib.py` (ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, dtype codes; `stream` is a hipStream_t passed as void*.
+ *   - every function returns CM3P_OK (0) or a negative CM3P_ERR_* code; nothing throws, nothing allocates,
+ *     nothing synchronises; workspaces are passed in by the caller; no global state.
+ *   - all pointers are device pointers, 16-byte aligned; "bf16" buffers are raw uint16 bit patterns.
+ *   - activations are row-major [tokens, features]; tokens = batch * seq.
+ *   - a function may be called from any host thread as long as the caller owns the stream.
+ */
+#ifndef CM3P_HIP_H
+#define CM3P_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM3P_OK 0
+#define CM3P_ERR_INVALID (-1) /* bad argument: null pointer, unsupported shape, misaligned buffer */
+#define CM3P_ERR_LAUNCH (-2)  /* the HIP runtime refused the launch */
+
+#define CM3P_F32 0
+#define CM3P_BF16 1
+
+/* ABI version of this header; cm3p_abi_version() must return it. */
+#define CM3P_ABI_VERSION 1
+int cm3p_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * LayerNorm without bias: y = (x - mean) / sqrt(var + eps) * weight.
+ * Replaces nn.LayerNorm(H, eps, bias=False) at TF:models/modernbert/modeling_modernbert.py:61,312,314,420.
+ * x: [rows, H] (fp32 or bf16).  Writes y_f32 and/or y_bf16 (either may be NULL), mean/rstd [rows] (may be NULL).
+ * H % 4 == 0, H <= 2048.
+ */
+int cm3p_layernorm_fwd(const void* x, int x_dtype, const float* weight, float* y_f32, void* y_bf16, float* mean,
+                       float* rstd, int64_t rows, int H, float eps, void* stream);
+
+/* Number of rows of `dw_partial` ([blocks, H] fp32 workspace) that cm3p_layernorm_bwd / cm3p_embed_ln_bwd need. */
+int cm3p_layernorm_bwd_blocks(int64_t rows);
+
+/* Backward of the above (autograd of the same nn.LayerNorm).  dx = dres + LN'(dy) where `dres` (may be NULL) is the
+ * gradient already flowing on the residual stream: the pre-norm residual x + f(LN(x)) of
+ * TF:...modeling_modernbert.py:331-332.  dx_f32 may alias dres.  dw[H] is fully overwritten. */
+int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* weight, const float* mean,
+                       const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw_partial, float* dw,
+                       int64_t rows, int H, void* stream);
+
+/* Token embedding lookup + optional audio-embedding scatter + LayerNorm.
+ * Replaces ModernBertEmbeddings.forward (TF:...modeling_modernbert.py:64-71) fed by
+ * CM3PBeatmapTransformer.forward's `inputs_embeds[input_ids == audio_token_id] = audio_embeds`
+ * (ref:cm3p/modeling_cm3p.py:592,603-605).  slot[t] >= 0 selects override_rows[slot[t]] instead of table[ids[t]];
+ * slot / override_rows may both be NULL. */
+int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
+                      const void* override_rows, int override_dtype, const float* weight, float* y_f32, void* y_bf16,
+                      float* mean, float* rstd, int64_t T, int H, float eps, void* stream);
+
+/* Backward: d_table[ids[t]] += row gradient (fp32 atomics; the caller zeroes d_table; row `padding_idx` gets none,
+ * as nn.Embedding(padding_idx=...) does), d_override[slot[t]] = row gradient.  Either may be NULL. */
+int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
+                      const void* override_rows, int override_dtype, const float* weight, const float* mean,
+                      const float* rstd, float* d_table, float* d_override, float* dw_partial, float* dw, int64_t T, int H,
+                      int64_t padding_idx, void* stream);
+
+/* slot[t] = rank of token t among the tokens equal to audio_token_id, in row-major (b, s) order, else -1;
+ * count[0] = how many there are.  The integer side of ref:cm3p/modeling_cm3p.py:604-605 (bit-exact). */
+int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int32_t* slot, int32_t* count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fp32 accumulation:  C[m, n] = sum_k A(m, k) * B(n, k)   (+ R[m, n])
+ * Replaces the bias-free nn.Linear calls Wqkv / Wo / Wi / Wo (TF:...modeling_modernbert.py:84,87,246,259,271,300,90-91)
+ * and their autograd: forward y = x W^T (a_kc=1, b_kc=1), input gradient dx = dy W (a_kc=1, b_kc=0) and
+ * weight gradient dW = dy^T x (a_kc=0, b_kc=0).
+ *   a_kc = 1: A is [M, lda] with k contiguous;   a_kc = 0: A is [K, lda] with m contiguous (element (m,k) at A[k*lda+m]).
+ *   b_kc likewise for B over (n, k).
+ *   epilogue: CM3P_EPI_BF16 (C bf16), CM3P_EPI_F32 (C fp32), CM3P_EPI_F32_RESID (C fp32 = R + acc; R fp32 [M, ldc], may
+ *   alias C).  Constraints: contiguous extents and leading dimensions are multiples of 8 elements.
+ */
+#define CM3P_EPI_BF16 0
+#define CM3P_EPI_F32 1
+#define CM3P_EPI_F32_RESID 2
+/* split_k > 1 (CM3P_EPI_F32 only, ldc == N): the contraction is cut into split_k ranges whose fp32 partial tiles go to
+ * `workspace` (split_k * M * N floats) and are then summed in a fixed order - used for dW, whose contraction runs over
+ * all tokens while its output is only a few hundred tiles. */
+int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                   int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
+
+/* fp32 -> bf16 cast of n elements (n % 4 == 0): the autocast weight / activation cast in front of a bf16 linear. */
+int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+/* y_f32 (and y_bf16 if not NULL) = a_f32 + b (b fp32 or bf16); n % 4 == 0.  Residual-gradient join for layer 0,
+ * whose attn_norm is nn.Identity (TF:...modeling_modernbert.py:309-310). */
+int cm3p_add_f32(const float* a, const void* b, int b_dtype, float* y_f32, void* y_bf16, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Rotary position embedding.
+ * cm3p_rope_table: cos/sin[p, j] = cos/sin(float(position_ids[p]) * inv_freq[j]), j < half_dim, fp32
+ *   (ModernBertRotaryEmbedding.forward, TF:...modeling_modernbert.py:146-163; the caller supplies inv_freq computed
+ *   as :141).
+ * cm3p_rope_apply: in place on the q and k thirds of a packed qkv buffer [B, S, 3, nh, 64] (bf16):
+ *   x' = x*cos + rotate_half(x)*sin in fp32, rounded back to bf16 (apply_rotary_pos_emb, :196-219).
+ *   pos_batch_stride = 0 when one position row serves every batch element, else S.  inverse != 0 applies the
+ *   transpose rotation (the backward pass).
+ */
+int cm3p_rope_table(const int64_t* position_ids, int64_t n_pos, const float* inv_freq, int half_dim, float* cos_out,
+                    float* sin_out, void* stream);
+int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B, int S, int nh, int64_t pos_batch_stride,
+                    int inverse, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Non-causal flash attention, head_dim 64, bf16 in / fp32 softmax / bf16 out.
+ * Replaces sdpa_attention_forward -> F.scaled_dot_product_attention(q, k, v, attn_mask, scale, is_causal=False)
+ * (TF:integrations/sdpa_attention.py:153-163, called from TF:...modeling_modernbert.py:286-297) together with the
+ * mask the reference materialises (TF:masking_utils.py:141-179): key kv is visible to query q of batch b iff
+ *   key_mask[b, kv] != 0  AND  (window < 0  OR  |q - kv| <= window).
+ * The (B,1,S,S) mask is never built.  Rows with no visible key produce exact zeros.
+ *   qkv: [B, S, 3, nh, 64] bf16 (q and k already rotated);  out: [B, S, nh, 64] bf16;  lse: [B, nh, S] fp32
+ *   (natural-log sum-exp of the scaled scores; +inf for rows with no visible key);  key_mask: [B, S] bytes or NULL.
+ */
+int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
+                  float scale, void* stream);
+/* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten. */
+int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GeGLU: g = gelu_erf(h[:, :I]) * h[:, I:]   (ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91).
+ * h: [T, 2I] bf16, g: [T, I] bf16; I % 8 == 0.  Backward: dh from dg and h.
+ */
+int cm3p_geglu_fwd(const void* h, void* g, int64_t T, int I, void* stream);
+int cm3p_geglu_bwd(const void* dg, const void* h, void* dh, int64_t T, int I, void* stream);
+/* y = gelu_erf(x) elementwise on bf16, and dx = dy * gelu'(x)  (nn.functional.gelu at ref:cm3p/modeling_cm3p.py:478,501-502). */
+int cm3p_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int cm3p_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pooling of the last hidden state (ref:cm3p/modeling_cm3p.py:385-396, 631-642).
+ *   cls != 0: pooled[b] = h[b, 0];  else pooled[b] = sum_s h[b,s]*m[b,s] / max(sum_s m[b,s], 1e-9)  (m all ones if NULL).
+ * h: [Bn, S, H] fp32, mask: [Bn, S] int64 or NULL, pooled: [Bn, H] fp32.  partial: fp32 workspace
+ * [Bn, cm3p_pool_chunks(S), H]; count: [Bn] fp32, sum of the mask row (saved for the backward pass).
+ */
+int cm3p_pool_chunks(int S);
+int cm3p_pool_fwd(const float* h, const int64_t* mask, float* pooled, float* partial, float* count, int Bn, int S, int H,
+                  int cls, void* stream);
+int cm3p_pool_bwd(const float* dpooled, const int64_t* mask, const float* count, float* dh, int Bn, int S, int H, int cls,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Contrastive head, fp32 throughout (ref:cm3p/modeling_cm3p.py:27-62, 958-985).
+ */
+/* C[m, n] (+)= alpha * sum_k A[m*a_rs + k*a_cs] * B[n*b_rs + k*b_cs]; generic strides, small problems only. */
+int cm3p_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_rs, int64_t a_cs, int64_t b_rs,
+                  int64_t b_cs, int64_t ldc, float alpha, int accumulate, void* stream);
+/* y = x / sqrt(sum x^2) per row, no eps (_get_vector_norm, ref:cm3p/modeling_cm3p.py:54-62,960,972); norm[rows] saved. */
+int cm3p_l2norm_fwd(const float* x, float* y, float* norm, int rows, int D, void* stream);
+int cm3p_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, int rows, int D, void* stream);
+/* Cross-entropy over `rows` rows of `cols` logits addressed as logits[row_offset[r] + c*col_stride]
+ * (row_offset NULL -> r*row_stride), target[r] in [0, cols): nn.functional.cross_entropy (ref:cm3p/modeling_cm3p.py:27-29)
+ * on a strided view, so `similarity`, `similarity.t()`, `similarity[arange, idx]` and
+ * `similarity.permute(2,0,1).reshape(B,-1)` (:41-50) need no copies.
+ * loss_rows[r] = logsumexp - logit[target].  If dlogits != NULL: dlogits[same address] += grad_scale * (softmax - onehot). */
+int cm3p_cross_entropy(const float* logits, int rows, int cols, int64_t row_stride, int64_t col_stride,
+                       const int64_t* row_offset, const int64_t* target, float grad_scale, float* loss_rows, float* dlogits,
+                       void* stream);
+/* y = x * exp(*log_scale): `logits * self.logit_scale.exp()` (ref:cm3p/modeling_cm3p.py:977) without a host read. */
+int cm3p_scale_exp(const float* x, const float* log_scale, float* y, int64_t n, void* stream);
+/* out[0] = sum a[i]*b[i] (fixed order): d logit_scale = <dlogits, logits>. */
+int cm3p_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out[0] (+)= scale * sum x[i] (fixed order): the mean over rows inside cross_entropy and the /2 of cm3p_loss. */
+int cm3p_sum_f32(const float* x, float* out, int64_t n, float scale, int accumulate, void* stream);
+/* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
+int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CM3P_HIP_H */

@@ -1,0 +1,348 @@
+"""Per-kernel parity tests: every C-ABI entry point against a torch fp32 CPU restatement of the same op.
+
+Run on the GPU box: python -m pytest tests -m gpu.  bf16 inputs are rounded first and handed to both sides, so the
+tolerances below only cover accumulation order and the final rounding of the output dtype (stated per test).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from cm3p_amd import kernels
+
+    return kernels
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _err(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item()
+
+
+def _assert_close(got, want, atol, rtol, what):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    bad = (got - want).abs() > atol + rtol * want.abs()
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max|err|={(got - want).abs().max():.4g}, "
+            f"first at {idx}: got {got[tuple(idx)]:.6g} want {want[tuple(idx)]:.6g}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (256, 384, 192), (200, 72, 96), (1000, 2304, 768), (130, 8, 8)])
+def test_gemm_forward_layout(K, M, N, K_):
+    """y = x W^T.  Asymmetric integer-valued data makes any row/col or k-order mix-up show as O(1) errors."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randint(-4, 5, (M, K_), generator=g).float()
+    w = torch.randint(-4, 5, (N, K_), generator=g).float()
+    want = x @ w.t()  # exact in fp32 and in the MFMA (small integers)
+    got = K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 1)  # EPI_F32
+    _assert_close(got, want, 0, 0, "fwd f32")
+    got16 = K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 0)
+    _assert_close(got16, want.to(torch.bfloat16), 0, 0, "fwd bf16")
+    r = torch.randn(M, N, generator=g)
+    gotr = K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 2, resid=r.to(DEV))
+    _assert_close(gotr, want + r, 1e-5, 1e-6, "fwd resid")
+
+
+@pytest.mark.parametrize("T,N,K_", [(128, 128, 128), (256, 192, 64), (200, 72, 96), (1024, 768, 2304)])
+def test_gemm_dgrad_layout(K, T, N, K_):
+    """dx[T,K] = dy[T,N] W[N,K]: B operand is contraction-strided (transposed LDS reads)."""
+    g = torch.Generator().manual_seed(T + N)
+    dy = torch.randint(-4, 5, (T, N), generator=g).float()
+    w = torch.randint(-4, 5, (N, K_), generator=g).float()
+    got = K.gemm(_bf(dy).to(DEV), _bf(w).to(DEV), T, K_, N, True, False, 1)
+    _assert_close(got, dy @ w, 0, 0, "dgrad")
+
+
+@pytest.mark.parametrize("T,N,K_,split", [(128, 128, 128, 1), (512, 192, 64, 1), (777, 72, 96, 3), (4096, 768, 384, 4)])
+def test_gemm_wgrad_layout(K, T, N, K_, split):
+    """dW[N,K] = dy[T,N]^T x[T,K]: both operands contraction-strided; split-K combine is exact for integers."""
+    g = torch.Generator().manual_seed(T + N + 1)
+    dy = torch.randint(-3, 4, (T, N), generator=g).float()
+    x = torch.randint(-3, 4, (T, K_), generator=g).float()
+    got = K.gemm(_bf(dy).to(DEV), _bf(x).to(DEV), N, K_, T, False, False, 1, split_k=split)
+    _assert_close(got, dy.t() @ x, 0, 0, "wgrad")
+
+
+def test_gemm_random_tolerance(K):
+    """Random normal data: bf16 inputs, fp32 accumulation; error bound 2e-3 relative to sqrt(K)."""
+    g = torch.Generator().manual_seed(3)
+    x = _bf(torch.randn(512, 768, generator=g))
+    w = _bf(torch.randn(1152, 768, generator=g))
+    want = x.float() @ w.float().t()
+    got = K.gemm(x.to(DEV), w.to(DEV), 512, 1152, 768, True, True, 1)
+    _assert_close(got, want, 2e-3 * math.sqrt(768), 0, "random fwd")
+
+
+def test_gemm_rejects_bad_arguments(K):
+    from cm3p_amd._lib import Cm3pHipError
+
+    x = torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV)  # K = 12 is not a multiple of 8
+    with pytest.raises(Cm3pHipError):
+        K.gemm(x, x, 16, 16, 12, True, True, 0)
+    with pytest.raises(Cm3pHipError):
+        K.gemm(x.cpu(), x.cpu(), 16, 16, 12, True, True, 0)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / embedding
+@pytest.mark.parametrize("rows,H", [(5, 64), (1000, 768), (37, 256), (4, 2048)])
+def test_layernorm_fwd_bwd(K, rows, H):
+    g = torch.Generator().manual_seed(rows + H)
+    x = torch.randn(rows, H, generator=g) * 2 + 0.5
+    w = 1 + 0.2 * torch.randn(H, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (H,), wr, None, 1e-5)
+    dy = torch.randn(rows, H, generator=g)
+    dres = torch.randn(rows, H, generator=g)
+    y.backward(dy)
+    y32, y16, mean, rstd = K.layernorm_fwd(x.to(DEV), w.to(DEV), 1e-5, True, True)
+    _assert_close(y32, y.detach(), 2e-5, 1e-5, "ln y f32")
+    _assert_close(y16, y.detach().to(torch.bfloat16), 1e-4, 8e-3, "ln y bf16")  # one bf16 ulp
+    dx32, dx16, dw = K.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dres.to(DEV), True)
+    _assert_close(dx32, xr.grad + dres, 5e-5, 1e-5, "ln dx")
+    _assert_close(dw, wr.grad, 2e-4 * math.sqrt(rows), 1e-5, "ln dw")
+    # bf16 dy path
+    dy16 = _bf(dy)
+    xr.grad = None
+    wr.grad = None
+    F.layer_norm(xr, (H,), wr, None, 1e-5).backward(dy16.float())
+    dx32b, _, dwb = K.layernorm_bwd(dy16.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None, False)
+    _assert_close(dx32b, xr.grad, 5e-5, 1e-5, "ln dx (bf16 dy)")
+    _assert_close(dwb, wr.grad, 2e-4 * math.sqrt(rows), 1e-5, "ln dw (bf16 dy)")
+
+
+def test_embed_ln_with_audio_override(K):
+    g = torch.Generator().manual_seed(11)
+    V, H, B, S = 50, 128, 3, 40
+    audio_id = 49
+    table = torch.randn(V, H, generator=g)
+    table[0] = 0
+    w = 1 + 0.1 * torch.randn(H, generator=g)
+    ids = torch.randint(0, V - 1, (B, S), generator=g)
+    ids[:, 1:7] = audio_id
+    ids[2, 20:23] = audio_id
+    n_audio = int((ids == audio_id).sum())
+    audio = torch.randn(n_audio, H, generator=g)
+
+    tr = table.clone().requires_grad_(True)
+    ar = audio.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    emb = F.embedding(ids, tr, padding_idx=0).clone()
+    emb[ids == audio_id] = ar
+    y = F.layer_norm(emb, (H,), wr, None, 1e-5)
+    dy = torch.randn(B, S, H, generator=g)
+    y.backward(dy)
+
+    slot, count = K.audio_slots(ids.to(DEV), audio_id)
+    want_slot = torch.where(ids.flatten() == audio_id, torch.cumsum((ids.flatten() == audio_id).int(), 0) - 1, -1)
+    assert torch.equal(slot.cpu().long(), want_slot.long())  # integer indexing is bit-exact
+    assert int(count.item()) == n_audio
+    y32, y16, mean, rstd = K.embed_ln_fwd(ids.to(DEV), table.to(DEV), w.to(DEV), 1e-5, slot, audio.to(DEV), want_bf16=True)
+    _assert_close(y32.view(B, S, H), y.detach(), 2e-5, 1e-5, "embed ln")
+    d_table, d_audio, dw = K.embed_ln_bwd(dy.reshape(-1, H).to(DEV), ids.to(DEV), table.to(DEV), w.to(DEV), mean, rstd, 0, slot,
+                                          audio.to(DEV))
+    _assert_close(d_table, tr.grad, 1e-4, 1e-5, "embed d_table")
+    assert d_table[0].abs().max().item() == 0.0  # padding row gets no gradient
+    _assert_close(d_audio, ar.grad, 1e-4, 1e-5, "embed d_audio")
+    _assert_close(dw, wr.grad, 1e-3, 1e-5, "embed dw")
+
+
+# ------------------------------------------------------------------------------------------------ RoPE / GeGLU / pool
+@pytest.mark.parametrize("per_batch", [False, True])
+def test_rope_matches_reference_formula(K, per_batch):
+    from oracle import cm3p_oracle as O
+
+    g = torch.Generator().manual_seed(5)
+    B, S, nh = 2, 300, 3
+    qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g))
+    pos = torch.arange(S).unsqueeze(0)
+    if per_batch:
+        pos = torch.stack([torch.arange(S), torch.arange(S) * 3 + 5])
+    cos_w, sin_w = O.rope_cos_sin(pos, 160000.0, 64)
+    q = qkv[:, :, 0].transpose(1, 2).float()
+    k = qkv[:, :, 1].transpose(1, 2).float()
+    q2, k2 = O.apply_rope(q, k, cos_w, sin_w)
+
+    inv_freq = O.rope_inv_freq(160000.0, 64)
+    cos, sin = K.rope_table(pos.to(DEV), inv_freq.to(DEV))
+    _assert_close(cos.view(pos.shape[0], S, 32), cos_w[..., :32], 2e-6, 0, "cos table")
+    _assert_close(sin.view(pos.shape[0], S, 32), sin_w[..., :32], 2e-6, 0, "sin table")
+    buf = qkv.clone().to(DEV)
+    K.rope_apply_(buf, cos, sin, B, S, nh, per_batch)
+    _assert_close(buf[:, :, 0].transpose(1, 2), q2.to(torch.bfloat16), 1e-4, 8e-3, "rope q")
+    _assert_close(buf[:, :, 1].transpose(1, 2), k2.to(torch.bfloat16), 1e-4, 8e-3, "rope k")
+    assert torch.equal(buf[:, :, 2].cpu(), qkv[:, :, 2])  # v untouched
+    # inverse rotation is the transpose: rotating back returns the input up to bf16 rounding
+    K.rope_apply_(buf, cos, sin, B, S, nh, per_batch, inverse=True)
+    _assert_close(buf[:, :, :2], qkv[:, :, :2], 2e-2, 2e-2, "rope inverse")
+
+
+def test_geglu_and_gelu(K):
+    g = torch.Generator().manual_seed(9)
+    T, I = 333, 192
+    h = _bf(torch.randn(T, 2 * I, generator=g) * 2)
+    hr = h.float().requires_grad_(True)
+    a, b = hr.chunk(2, dim=-1)
+    y = F.gelu(a) * b
+    dg = _bf(torch.randn(T, I, generator=g))
+    y.backward(dg.float())
+    got = K.geglu_fwd(h.to(DEV))
+    _assert_close(got, y.detach().to(torch.bfloat16), 1e-6, 8e-3, "geglu fwd")
+    dh = K.geglu_bwd(dg.to(DEV), h.to(DEV))
+    _assert_close(dh, hr.grad.to(torch.bfloat16), 1e-5, 8e-3, "geglu bwd")
+    x = _bf(torch.randn(64, 128, generator=g) * 3)
+    xr = x.float().requires_grad_(True)
+    F.gelu(xr).backward(torch.ones(64, 128))
+    _assert_close(K.gelu_fwd(x.to(DEV)), F.gelu(x.float()).to(torch.bfloat16), 1e-6, 8e-3, "gelu fwd")
+    _assert_close(K.gelu_bwd(torch.ones(64, 128, dtype=torch.bfloat16, device=DEV), x.to(DEV)), xr.grad.to(torch.bfloat16),
+                  1e-5, 8e-3, "gelu bwd")
+
+
+@pytest.mark.parametrize("cls,use_mask", [(True, True), (False, True), (False, False)])
+def test_pooling(K, cls, use_mask):
+    from oracle import cm3p_oracle as O
+
+    g = torch.Generator().manual_seed(13)
+    Bn, S, H = 5, 300, 128
+    h = torch.randn(Bn, S, H, generator=g)
+    lens = torch.tensor([300, 1, 150, 299, 0])
+    mask = (torch.arange(S)[None] < lens[:, None]).long() if use_mask else None
+    hr = h.clone().requires_grad_(True)
+    want = O.pool(hr, mask, cls)
+    dp = torch.randn(Bn, H, generator=g)
+    want.backward(dp)
+    pooled, count = K.pool_fwd(h.to(DEV), mask.to(DEV) if use_mask else None, Bn, S, cls)
+    _assert_close(pooled, want.detach(), 1e-5, 1e-5, "pool fwd")
+    dh = K.pool_bwd(dp.to(DEV), mask.to(DEV) if use_mask else None, count, Bn, S, cls)
+    _assert_close(dh.view(Bn, S, H), hr.grad, 1e-6, 1e-5, "pool bwd")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True):
+    from oracle import cm3p_oracle as O
+
+    g = torch.Generator().manual_seed(seed)
+    qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g))
+    mask = None
+    if lens is not None:
+        mask = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).long()
+    allowed = O.attention_allowed(mask, B, S, window if window >= 0 else None)
+    if allowed is None and window >= 0:
+        allowed = torch.ones(B, 1, S, S, dtype=torch.bool)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    o = O.sdpa(q, k, v, allowed, 0.125, eager=True).transpose(1, 2).reshape(B * S, nh * 64)
+    do = _bf(torch.randn(B * S, nh * 64, generator=g))
+    o.backward(do.float())
+
+    km = mask.to(torch.uint8).to(DEV) if mask is not None else None
+    out, lse = K.attn_fwd(qkv.to(DEV), km, B, S, nh, window, 0.125)
+    _assert_close(out, o.detach().to(torch.bfloat16), 2e-3, 2e-2, f"attn fwd S={S} w={window}")
+    # rows with no visible key are exact zeros
+    if allowed is not None:
+        dead = ~allowed.any(dim=-1).expand(B, nh, S).transpose(1, 2).reshape(B * S, nh)  # (B*S, nh)
+        if dead.any():
+            assert out.view(B * S, nh, 64).cpu()[dead].abs().max().item() == 0.0
+            assert torch.isinf(lse.cpu().transpose(1, 2).reshape(B * S, nh)[dead]).all()
+    if check_bwd:
+        dqkv = K.attn_bwd(qkv.to(DEV), out, do.to(DEV), lse, km, B, S, nh, window, 0.125)
+        want = x.grad
+        scale = want.abs().max().item()
+        _assert_close(dqkv, want, 2e-2 * scale, 3e-2, f"attn bwd S={S} w={window}")
+        for i, nm in enumerate("qkv"):
+            e = (dqkv[:, :, i].float().cpu() - want[:, :, i]).norm() / want[:, :, i].norm().clamp_min(1e-9)
+            assert e < 2e-2, f"d{nm} relative L2 error {e:.3e}"
+
+
+def test_attention_global_nopad(K):
+    _attn_case(K, 2, 256, 2, -1, None, 1)
+
+
+def test_attention_global_padded_ragged(K):
+    _attn_case(K, 3, 203, 2, -1, [203, 100, 7], 2)
+
+
+def test_attention_sliding_window(K):
+    _attn_case(K, 2, 512, 2, 64, None, 3)
+
+
+def test_attention_sliding_window_padded_dead_rows(K):
+    # row 1 is valid for 100 keys only: queries >= 165 see no key in a +-64 window -> exact zeros
+    _attn_case(K, 2, 384, 2, 64, [384, 100], 4)
+
+
+def test_attention_short_sequence(K):
+    _attn_case(K, 2, 48, 1, 64, None, 5)
+    _attn_case(K, 1, 1, 1, -1, None, 6)
+
+
+def test_attention_long_sequence_properties(K):
+    """S = 8192 (BASELINE config 4 length): too big for the O(S^2) oracle in a test, so check properties:
+    softmax rows are convex combinations (|out| <= max|v|), lse is finite, and a window-64 run at S = 8192 equals a
+    window-64 run on an S = 1024 slice for queries far from the cut."""
+    g = torch.Generator().manual_seed(8)
+    S, nh = 8192, 1
+    qkv = _bf(torch.randn(1, S, 3, nh, 64, generator=g)).to(DEV)
+    out, lse = K.attn_fwd(qkv, None, 1, S, nh, -1, 0.125)
+    assert torch.isfinite(lse).all() and torch.isfinite(out.float()).all()
+    assert out.float().abs().max() <= qkv[:, :, 2].float().abs().max() + 1e-2
+    out_w, _ = K.attn_fwd(qkv, None, 1, S, nh, 64, 0.125)
+    sl = qkv[:, 2048:3072].contiguous()
+    out_s, _ = K.attn_fwd(sl, None, 1, 1024, nh, 64, 0.125)
+    a = out_w.view(S, 64)[2048 + 64:3072 - 64].float()
+    b = out_s.view(1024, 64)[64:-64].float()
+    assert (a - b).abs().max().item() == 0.0  # same tiles, same arithmetic -> bit-identical
+
+
+# ------------------------------------------------------------------------------------------------ fp32 head
+def test_head_kernels(K):
+    g = torch.Generator().manual_seed(21)
+    a = torch.randn(37, 70, generator=g)
+    b = torch.randn(53, 70, generator=g)
+    got = K.gemm_f32(a.to(DEV), b.to(DEV), 37, 53, 70, (70, 1), (70, 1), alpha=0.5)
+    _assert_close(got, 0.5 * a @ b.t(), 1e-5, 1e-5, "gemm_f32 NT")
+    at = torch.randn(70, 37, generator=g)
+    got = K.gemm_f32(at.to(DEV), b.to(DEV), 37, 53, 70, (1, 37), (70, 1))
+    _assert_close(got, at.t() @ b.t(), 1e-5, 1e-5, "gemm_f32 TN")
+
+    x = torch.randn(9, 512, generator=g)
+    xr = x.clone().requires_grad_(True)
+    from oracle import cm3p_oracle as O
+
+    y = O.l2_normalize(xr)
+    dy = torch.randn(9, 512, generator=g)
+    y.backward(dy)
+    yy, nrm = K.l2norm_fwd(x.to(DEV))
+    _assert_close(yy, y.detach(), 1e-6, 1e-5, "l2norm fwd")
+    _assert_close(K.l2norm_bwd(dy.to(DEV), yy, nrm), xr.grad, 1e-6, 1e-4, "l2norm bwd")
+
+    classes = torch.tensor([[1, 0, 2], [0, 0, 3], [2, 3, -1], [3, 1, 0]])
+    assert K.first_zero_index(classes.to(DEV)).cpu().tolist() == O.true_variation_index(classes).tolist()
+
+    L = torch.randn(12, 12, generator=g) * 3
+    Lr = L.clone().requires_grad_(True)
+    loss = O.cm3p_loss(Lr)
+    loss.backward()
+    d = torch.zeros(12, 12, device=DEV)
+    tgt = torch.arange(12, device=DEV)
+    lr = K.cross_entropy(L.to(DEV), 12, 12, 12, 1, tgt, None, 0.5 / 12, d)
+    lc = K.cross_entropy(L.to(DEV), 12, 12, 1, 12, tgt, None, 0.5 / 12, d)
+    got_loss = K.sum_f32(lr, 0.5 / 12)
+    K.sum_f32(lc, 0.5 / 12, out=got_loss, accumulate=True)
+    _assert_close(got_loss, loss.detach().reshape(1), 1e-6, 1e-6, "clip loss")
+    _assert_close(d, Lr.grad, 1e-7, 1e-5, "clip dlogits")
