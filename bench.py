@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CM3P contrastive training step (dual-tower forward + in-batch CLIP loss + backward) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W                    # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                       # N > 1, one rank per GPU over RCCL
+
+A step is one pass of the hot path over one synthetic batch already resident in HBM: forward of both towers, projections,
+L2 norm, logits, symmetric cross-entropy, full backward (optimizer excluded).  Workload at every N is
+BASELINE.json configs[1] per GPU ("C2": default CM3P config, beatmap seq 4096 / metadata seq 256, bf16 GEMM operands,
+batch 32 per GPU); for N > 1 the batch is sharded over ranks (weak scaling), embeddings are all-gathered for global
+in-batch negatives and gradients are all-reduced (configs[2], "C3").  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (largest share of step time), timed live with HIP events on the launching stream
+                over the timed steps: algorithmic FLOPs per launch / average launch duration vs the dense bf16 MFMA peak.
+  cpu_baseline  the CPU oracle (oracle/cm3p_oracle.py: the reference's fp32 sdpa path restated) timed on the host's cores on
+                a bounded sample of the same workload, rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+
+WORKLOADS = {
+    # name: (per-GPU batch, beatmap seq, metadata seq, audio frames or None)
+    "c2": dict(B=32, S=4096, L=256, audio_T=None, desc="default CM3P config, beatmap seq=4096, metadata seq=256, batch 32/GPU"),
+    "c4": dict(B=16, S=8192, L=256, audio_T=None, desc="default CM3P config, beatmap seq=8192, metadata seq=256, batch 16/GPU"),
+    "c5": dict(B=32, S=4096, L=256, audio_T=1600, desc="default CM3P config + audio-fused path (1600 mel frames), batch 32/GPU"),
+}
+
+
+def tower_flops_fwd(cfg, tokens: int, S: int) -> float:
+    """Algorithmic matmul FLOPs of one encoder forward: per token per layer 8H^2 + 6HI for the four
+    linears plus 4*k*H for attention with k = S (global) or min(S, 2*half_window+1) (local band at its true width)."""
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    total = 0.0
+    for i in range(L):
+        k = S if cfg.is_global_layer(i) else min(S, 2 * cfg.half_window + 1)
+        total += 8.0 * H * H + 6.0 * H * I + 4.0 * k * H
+    return total * tokens
+
+
+def step_flops(config, w) -> float:
+    B, S, L = w["B"], w["S"], w["L"]
+    f = tower_flops_fwd(config.beatmap_config, B * S, S) + tower_flops_fwd(config.metadata_config, B * L, L)
+    if w["audio_T"]:
+        T2 = w["audio_T"] // 2
+        f += tower_flops_fwd(config.beatmap_config.audio_config, B * T2, T2)
+    return 3.0 * f  # backward = 2 x forward, no recompute credit
+
+
+def make_batch(config, w, rank: int, device):
+    from cm3p_amd.synthetic import synthetic_batch
+
+    return {k: v.to(device) for k, v in synthetic_batch(config, w["B"], w["S"], w["L"], seed=1234 + rank, audio_T=w["audio_T"]).items()}
+
+
+def host_cores() -> int:
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box hands one GPU's
+    share of a large host, 16 cores, to the job; spawning one thread per visible core would oversubscribe it)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("CM3P_BENCH_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(workload: str) -> dict:
+    """Time the CPU oracle on a bounded sample: one sequence pair of the same lengths, fp32, all host cores."""
+    from oracle import cm3p_oracle as O
+
+    w = WORKLOADS[workload]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} host threads ...", file=sys.stderr, flush=True)
+    cfg = {}
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point) for k, v in O.init_state_dict(cfg, seed=0, with_audio=bool(w["audio_T"])).items()}
+    Bc = 1
+    batch = O.synthetic_batch(cfg, Bc, w["S"], w["L"], seed=1234, audio_T=w["audio_T"])
+    # thread-pool warm-up on a tiny shape, then ONE timed forward + backward
+    tiny = O.synthetic_batch(cfg, 1, 64, 16, seed=1)
+    O.forward(sd, cfg, **tiny)["loss"].backward()
+    t0 = time.perf_counter()
+    loss = O.forward(sd, cfg, **batch)["loss"]
+    print(f"[bench] cpu_baseline: forward {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline: forward+backward {dt:.1f} s", file=sys.stderr, flush=True)
+    return {
+        "value": Bc / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": f"1 step of B={Bc} at the same sequence lengths (beatmap {w['S']}, metadata {w['L']}), fp32 sdpa path, "
+                  f"{dt:.1f} s; the full B={w['B']} step does not fit host memory",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing in the timed region")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and cm3p_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from cm3p_amd import CM3PConfig, CM3PModel, _lib
+
+    w = WORKLOADS[args.workload]
+    config = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))  # ref:configs/model/default.yaml
+    torch.manual_seed(0)
+    model = CM3PModel(config).to(device).train()  # random init of the named architecture, fp32 master weights
+    if not w["audio_T"]:
+        for p in model.beatmap_model.audio_encoder.parameters():
+            p.requires_grad_(False)
+    step_model = model
+    if world > 1:
+        model.gather_negatives = True
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
+                                                               bucket_cap_mb=128)
+    batch = make_batch(config, w, rank, device)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = step_model(**batch)
+        out.loss.backward()
+        return out.loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    profile = not args.no_profile
+    fence()
+    if profile:
+        _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_end() if profile else {}
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    pairs_per_s = world * w["B"] * args.steps / elapsed
+    flops = step_flops(config, w)
+    result = {
+        "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",
+        "value": pairs_per_s,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "steps_per_s": 1e3 / ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {w['desc']}", "global_batch": world * w["B"], "beatmap_seq": w["S"],
+                   "metadata_seq": w["L"], "parallelism": f"dp{world}" + ("+allgather-negatives" if world > 1 else ""),
+                   "weights": "random init (reference init rules), fp32 master / bf16 GEMM operands", "loss": float(loss.item())},
+        "step_tflops_algorithmic": flops / 1e12,
+        "step_mfma_frac": flops / (ms_per_step * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+    }
+    if rank == 0:
+        if prof:
+            total_ms = sum(v[1] for v in prof.values())
+            tag, (n, ms, work) = max(prof.items(), key=lambda kv: kv[1][1])
+            achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            result["roofline"] = {
+                "kernel": tag, "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": n, "avg_launch_ms": ms / n, "share_of_kernel_time": ms / total_ms,
+                "flop_per_launch": work / n,
+            }
+            result["kernel_breakdown_ms_per_step"] = {
+                k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,7 @@ SIGNATURES = {
     "cm3p_cross_entropy": [_P, _I, _I, _L, _L, _P, _P, _F, _P, _P, _P],
     "cm3p_first_zero_index": [_P, _I, _I, _P, _P],
     "cm3p_scale_exp": [_P, _P, _P, _L, _P],
+    "cm3p_scale_by": [_P, _P, _P, _L, _P],
     "cm3p_dot_f32": [_P, _P, _P, _L, _P],
     "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
 }
@@ -109,8 +110,39 @@ def dt(t: torch.Tensor) -> int:
     raise Cm3pHipError(f"unsupported dtype {t.dtype}")
 
 
-def call(name: str, *args):
+# Optional per-launch timing with HIP events on the launching stream (bench.py's roofline leg).  When `_prof` is a list,
+# every call appends (tag, start_event, end_event, work) where `work` is the algorithmic flop (or byte) count the
+# caller attached.  Off (None) by default: zero overhead on the product path.
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> {tag: (launches, total_ms, total_work)} after synchronising."""
+    global _prof
+    rec, _prof = _prof or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for tag, e0, e1, work in rec:
+        n, ms, w = out.get(tag, (0, 0.0, 0.0))
+        out[tag] = (n + 1, ms + e0.elapsed_time(e1), w + (work or 0.0))
+    return out
+
+
+def call(name: str, *args, tag: str | None = None, work: float | None = None):
+    if _prof is None:
+        _check(getattr(load(), name)(*args), name)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
     _check(getattr(load(), name)(*args), name)
+    e1.record()
+    _prof.append((tag or name, e0, e1, work))
 
 
 def query(name: str, *args) -> int:

@@ -112,6 +112,13 @@ __global__ __launch_bounds__(256) void scale_exp_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * s;
 }
 
+// y[i] = x[i] * (*scale)
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       float* __restrict__ y, int64_t n) {
+    const float s = *scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * s;
+}
+
 // out[0] = sum_i a[i] * b[i], single block, fixed order
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                   int64_t n) {
@@ -181,6 +188,15 @@ int cm3p_scale_exp(const float* x, const float* log_scale, float* y, int64_t n, 
     int64_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     scale_exp_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, log_scale, y, n);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_scale_by(const float* x, const float* scale, float* y, int64_t n, void* stream) {
+    CM3P_REQUIRE(x && scale && y && n > 0);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    scale_by_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, scale, y, n);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

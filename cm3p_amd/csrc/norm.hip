@@ -155,13 +155,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// out[col] = sum_b partial[b][col], fixed summation order.
+// out[col] = sum_b partial[b][col], fixed summation order.  Block = 32 columns x 8 row slices; each thread keeps 8
+// independent loads in flight, slices are combined through LDS in slice order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= H) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * H + col];
-    out[col] = s;
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < H) {
+        const int per = (nblk + 7) / 8;
+        const int b0 = slice * per, b1 = min(nblk, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += partial[(int64_t)(b + u) * H + col];
+        }
+        for (; b < b1; ++b) acc[0] += partial[(int64_t)b * H + col];
+    }
+    red[slice][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (slice == 0 && col < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][cx];
+        out[col] = s;
+    }
 }
 
 // ---- embedding gather + LayerNorm ---------------------------------------------------------------------------
@@ -309,12 +327,13 @@ __global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __rest
     if (threadIdx.x == 0) count[0] = carry;
 }
 
-inline int ln_grid(int64_t rows) {
+inline int ln_grid(int64_t rows, int cap = 2048) {
     int64_t blocks = (rows + 3) / 4;
-    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    if (blocks > cap) blocks = cap;  // 256 CUs x 8 blocks, grid-stride the rest
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
+inline int ln_bwd_grid(int64_t rows) { return ln_grid(rows, 1024); }
 
 }  // namespace
 
@@ -334,7 +353,7 @@ int cm3p_layernorm_fwd(const void* x, int x_dtype, const float* weight, float* y
     return CM3P_OK;
 }
 
-int cm3p_layernorm_bwd_blocks(int64_t rows) { return ln_grid(rows); }
+int cm3p_layernorm_bwd_blocks(int64_t rows) { return ln_bwd_grid(rows); }
 
 int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* weight, const float* mean, const float* rstd,
                        const float* dres, float* dx_f32, void* dx_bf16, float* dw_partial, float* dw, int64_t rows, int H,
@@ -343,14 +362,14 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     CM3P_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 2048);
     CM3P_REQUIRE(dy_dtype == CM3P_F32 || dy_dtype == CM3P_BF16);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = ln_grid(rows);
+    const int grid = ln_bwd_grid(rows);
     const size_t lds = (size_t)4 * H * sizeof(float);
     if (dy_dtype == CM3P_BF16)
         layernorm_bwd_kernel<true><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
     else
         layernorm_bwd_kernel<false><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
     CM3P_LAUNCH_CHECK();
-    colsum_kernel<<<(H + 255) / 256, 256, 0, s>>>(dw_partial, dw, grid, H);
+    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -383,7 +402,7 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
     CM3P_REQUIRE(dy && ids && table && weight && mean && rstd && dw_partial && dw && T > 0 && H > 0 && H % 4 == 0 && H <= 2048);
     CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = ln_grid(T);
+    const int grid = ln_bwd_grid(T);
     const size_t lds = (size_t)4 * H * sizeof(float);
     const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
 #define CM3P_EMB_BWD(TB, OB)                                                                                          \
@@ -395,7 +414,7 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
     else CM3P_EMB_BWD(false, false);
 #undef CM3P_EMB_BWD
     CM3P_LAUNCH_CHECK();
-    colsum_kernel<<<(H + 255) / 256, 256, 0, s>>>(dw_partial, dw, grid, H);
+    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -1,0 +1,326 @@
+"""The ModernBERT-shaped encoder tower of CM3P on HIP kernels.
+
+`CM3PEncoder` stands where the reference instantiates `transformers.ModernBertModel`
+(ref:cm3p/modeling_cm3p.py:305,491,537) and keeps its parameter names, so `state_dict()` keys are unchanged:
+    embeddings.tok_embeddings.weight, embeddings.norm.weight, layers.N.{attn_norm,mlp_norm}.weight,
+    layers.N.attn.{Wqkv,Wo}.weight, layers.N.mlp.{Wi,Wo}.weight, final_norm.weight
+The nn.Linear / nn.LayerNorm / nn.Embedding members are parameter containers only; their torch forward is never
+called.  The whole layer stack is ONE autograd node (`_EncoderStackFn`) whose forward and backward are sequences of
+C-ABI launches (cm3p_amd/kernels.py), restating TF:models/modernbert/modeling_modernbert.py:262-333,434-478:
+
+    per layer:  xn = LN(x) [identity for layer 0] -> qkv = xn Wqkv^T -> RoPE(q,k) -> flash attention (global, or
+                |i-j| <= 64 band; key padding) -> x += o Wo^T -> xn = LN(x) -> h = xn Wi^T -> g = gelu(h[:I]) * h[I:]
+                -> x += g Wo^T;   after the last layer: final LN.
+
+Numerics: the residual stream, LayerNorm statistics, softmax and all accumulations are fp32; GEMM operands and saved
+activations are bf16 (what HF Trainer's bf16 autocast gives the reference's nn.Linear calls).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+
+Tensor = torch.Tensor
+
+
+def _check_supported(cfg):
+    H, nh = cfg.hidden_size, cfg.num_attention_heads
+    problems = []
+    if H % nh or H // nh != 64:
+        problems.append(f"head_dim must be 64 (hidden_size={H}, heads={nh})")
+    if getattr(cfg, "hidden_activation", "gelu") != "gelu":
+        problems.append("hidden_activation must be 'gelu'")
+    for flag in ("norm_bias", "attention_bias", "mlp_bias"):
+        if getattr(cfg, flag, False):
+            problems.append(f"{flag}=True is not supported (the reference configs never set it)")
+    for p in ("attention_dropout", "embedding_dropout", "mlp_dropout"):
+        if getattr(cfg, p, 0.0) != 0.0:
+            problems.append(f"{p} must be 0.0")
+    if cfg.intermediate_size % 8 or H % 8:
+        problems.append("hidden_size and intermediate_size must be multiples of 8")
+    if problems:
+        raise NotImplementedError("cm3p_amd HIP encoder: " + "; ".join(problems))
+
+
+class CM3PAttentionParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.Wqkv = nn.Linear(cfg.hidden_size, 3 * cfg.hidden_size, bias=False)
+        self.Wo = nn.Linear(cfg.hidden_size, cfg.hidden_size, bias=False)
+
+
+class CM3PMLPParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.Wi = nn.Linear(cfg.hidden_size, 2 * cfg.intermediate_size, bias=False)
+        self.Wo = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+
+class CM3PEncoderLayerParams(nn.Module):
+    def __init__(self, cfg, layer_idx: int):
+        super().__init__()
+        # layer 0 has no attn_norm (TF:...modeling_modernbert.py:309-310)
+        self.attn_norm = nn.Identity() if layer_idx == 0 else nn.LayerNorm(cfg.hidden_size, eps=cfg.norm_eps, bias=False)
+        self.attn = CM3PAttentionParams(cfg)
+        self.mlp_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.norm_eps, bias=False)
+        self.mlp = CM3PMLPParams(cfg)
+
+
+class CM3PEmbeddingParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.tok_embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size, padding_idx=getattr(cfg, "pad_token_id", None))
+        self.norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.norm_eps, bias=False)
+
+
+def _f32(w: Tensor) -> Tensor:
+    return w if w.dtype == torch.float32 else w.float()
+
+
+def _bf16_weight(w: Tensor) -> Tensor:
+    """bf16 GEMM operand of a master weight (what autocast's per-call cast produces)."""
+    w = w.detach()
+    return w if w.dtype == torch.bfloat16 else K.cast_bf16(w.contiguous())
+
+
+class _Geometry:
+    """Static description of one forward call of the stack (no tensors that need grad)."""
+
+    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save")
+
+
+class _EncoderStackFn(torch.autograd.Function):
+    """x0 [T,H] fp32 (already embedding-normed) + all layer weights -> final-normed hidden [T,H] fp32."""
+
+    @staticmethod
+    def forward(ctx, geo: _Geometry, x0: Tensor, *weights: Tensor):
+        B, S, H, nh, L = geo.B, geo.S, geo.H, geo.nh, geo.L
+        scale = 64 ** -0.5
+        it = iter(weights)
+        saved = []
+        x = x0
+        wb_all = []
+        for i in range(L):
+            w_an = None if i == 0 else _f32(next(it))
+            Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
+            Wqkv_b, Wo_b, Wi_b, Wo2_b = (_bf16_weight(w) for w in (Wqkv, Wo, Wi, Wo2))
+            cos, sin = geo.rope[i]
+            if i == 0:
+                xn, mean_a, rstd_a = K.cast_bf16(x), None, None
+            else:
+                _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, geo.save)
+            qkv = K.linear_fwd(xn, Wqkv_b)
+            K.rope_apply_(qkv, cos, sin, B, S, nh, geo.per_batch_pos)
+            o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
+            x_mid = K.linear_fwd(o, Wo_b, resid=x)
+            _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, geo.save)
+            h = K.linear_fwd(xn2, Wi_b)
+            g = K.geglu_fwd(h)
+            x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
+            if geo.save:
+                saved.append((x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g))
+                wb_all.append((w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b))
+            x = x_out
+        w_fn = _f32(next(it))
+        y, _, mean_f, rstd_f = K.layernorm_fwd(x, w_fn, geo.eps, True, False, geo.save)
+        if geo.save:
+            ctx.geo = geo
+            ctx.saved = saved
+            ctx.wb = wb_all
+            ctx.final = (x, w_fn, mean_f, rstd_f)
+            ctx.wdtypes = [w.dtype for w in weights]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        geo = ctx.geo
+        B, S, nh, L = geo.B, geo.S, geo.nh, geo.L
+        scale = 64 ** -0.5
+        need = ctx.needs_input_grad  # (geo, x0, *weights)
+        grads = []  # collected in reverse weight order
+
+        x_last, w_fn, mean_f, rstd_f = ctx.final
+        dy = dy.contiguous()
+        gx32, gx16, dw_fn = K.layernorm_bwd(dy, x_last, w_fn, mean_f, rstd_f, None, True, inplace=False)
+        grads.append(dw_fn)
+        for i in reversed(range(L)):
+            x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = ctx.saved[i]
+            w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb[i]
+            ctx.saved[i] = None  # release activations as we go
+            # ---- MLP branch: x_out = x_mid + g Wo2^T
+            dg = K.linear_dgrad(gx16, Wo2_b)
+            dWo2 = K.linear_wgrad(gx16, g)
+            dh = K.geglu_bwd(dg, h)
+            del dg, g
+            dxn2 = K.linear_dgrad(dh, Wi_b)
+            dWi = K.linear_wgrad(dh, xn2)
+            del dh, h, xn2
+            gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True)
+            del dxn2, x_mid
+            # ---- attention branch: x_mid = x + o Wo^T
+            do = K.linear_dgrad(gx16, Wo_b)
+            dWo = K.linear_wgrad(gx16, o)
+            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale)
+            del do, o, qkv
+            cos, sin = geo.rope[i]
+            K.rope_apply_(dqkv, cos, sin, B, S, nh, geo.per_batch_pos, inverse=True)
+            dxn = K.linear_dgrad(dqkv, Wqkv_b)
+            dWqkv = K.linear_wgrad(dqkv, xn)
+            del dqkv, xn
+            if i == 0:
+                gx32, _ = K.add_f32(gx32, dxn, want_bf16=False)
+                grads.extend([dWo2, dWi, dw_mn, dWo, dWqkv])
+            else:
+                gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True)
+                grads.extend([dWo2, dWi, dw_mn, dWo, dWqkv, dw_an])
+            del dxn
+        grads.reverse()
+        out = []
+        for gw, dtype, needed in zip(grads, ctx.wdtypes, need[2:]):
+            out.append((gw if gw.dtype == dtype else gw.to(dtype)) if needed else None)
+        ctx.saved = ctx.wb = ctx.final = None
+        return (None, gx32 if need[1] else None, *out)
+
+
+class _EmbedLNFn(torch.autograd.Function):
+    """LayerNorm(tok_embeddings[ids]) with optional audio rows scattered over the placeholder tokens
+    (TF:...modeling_modernbert.py:64-71, ref:cm3p/modeling_cm3p.py:592,603-605)."""
+
+    @staticmethod
+    def forward(ctx, ids: Tensor, table: Tensor, norm_w: Tensor, eps: float, padding_idx: int, slot: Optional[Tensor],
+                audio_rows: Optional[Tensor]):
+        w = _f32(norm_w.detach())
+        tab = table.detach()
+        ar = audio_rows.detach().contiguous() if audio_rows is not None else None
+        y, _, mean, rstd = K.embed_ln_fwd(ids, tab, w, eps, slot, ar)
+        ctx.pack = (ids, tab, w, mean, rstd, slot, ar, padding_idx)
+        ctx.dtypes = (table.dtype, norm_w.dtype, audio_rows.dtype if audio_rows is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        ids, tab, w, mean, rstd, slot, ar, padding_idx = ctx.pack
+        d_table, d_audio, dw = K.embed_ln_bwd(dy.contiguous(), ids, tab, w, mean, rstd, padding_idx, slot, ar,
+                                              want_table_grad=ctx.needs_input_grad[1])
+        td, wd, ad = ctx.dtypes
+        if d_table is not None and d_table.dtype != td:
+            d_table = d_table.to(td)
+        if d_audio is not None and d_audio.dtype != ad:
+            d_audio = d_audio.to(ad)
+        return None, d_table, dw.to(wd), None, None, None, d_audio
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """Plain LayerNorm of given rows (the `inputs_embeds` entry of ModernBertEmbeddings, TF:...modeling_modernbert.py:67-68)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, norm_w: Tensor, eps: float):
+        w = _f32(norm_w.detach())
+        xd = x.detach().contiguous()
+        y, _, mean, rstd = K.layernorm_fwd(xd, w, eps, True, False)
+        ctx.pack = (xd, w, mean, rstd)
+        ctx.dtypes = (x.dtype, norm_w.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        xd, w, mean, rstd = ctx.pack
+        x32 = xd if xd.dtype == torch.float32 else xd.float()
+        dx, _, dw = K.layernorm_bwd(dy.contiguous(), x32, w, mean, rstd, None, False, inplace=False)
+        return (dx if ctx.dtypes[0] == torch.float32 else dx.to(ctx.dtypes[0])), dw.to(ctx.dtypes[1]), None
+
+
+class CM3PEncoder(nn.Module):
+    """Drop-in for the `ModernBertModel` member of the reference towers (same submodule / parameter names)."""
+
+    def __init__(self, config):
+        super().__init__()
+        _check_supported(config)
+        self.config = config
+        self.embeddings = CM3PEmbeddingParams(config)
+        self.layers = nn.ModuleList([CM3PEncoderLayerParams(config, i) for i in range(config.num_hidden_layers)])
+        self.final_norm = nn.LayerNorm(config.hidden_size, eps=config.norm_eps, bias=False)
+        self._inv_freq_cache = {}
+        # init roles (TF:...modeling_modernbert.py:372-386): 'in'/'embedding' std = initializer_range,
+        # 'out' std = initializer_range / sqrt(2 L); consumed by CM3PPreTrainedModel._init_weights
+        cutoff = config.initializer_cutoff_factor or 3
+        std_in = config.initializer_range
+        std_out = config.initializer_range / (2.0 * config.num_hidden_layers) ** 0.5
+        self.embeddings.tok_embeddings._cm3p_init = (std_in, cutoff)
+        for layer in self.layers:
+            layer.attn.Wqkv._cm3p_init = (std_in, cutoff)
+            layer.attn.Wo._cm3p_init = (std_out, cutoff)
+            layer.mlp.Wi._cm3p_init = (std_in, cutoff)
+            layer.mlp.Wo._cm3p_init = (std_out, cutoff)
+
+    def get_input_embeddings(self):
+        return self.embeddings.tok_embeddings
+
+    def set_input_embeddings(self, value):
+        self.embeddings.tok_embeddings = value
+
+    def _inv_freq(self, theta: float, device) -> Tensor:
+        key = (float(theta), str(device))
+        if key not in self._inv_freq_cache:
+            # TF:...modeling_modernbert.py:141, evaluated on the host exactly as the reference does
+            inv = 1.0 / (theta ** (torch.arange(0, 64, 2, dtype=torch.float) / 64))
+            self._inv_freq_cache[key] = inv.to(device)
+        return self._inv_freq_cache[key]
+
+    def _stack_weights(self):
+        ws = []
+        for i, layer in enumerate(self.layers):
+            if i > 0:
+                ws.append(layer.attn_norm.weight)
+            ws += [layer.attn.Wqkv.weight, layer.attn.Wo.weight, layer.mlp_norm.weight, layer.mlp.Wi.weight, layer.mlp.Wo.weight]
+        ws.append(self.final_norm.weight)
+        return ws
+
+    def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                position_ids: Optional[Tensor] = None, inputs_embeds: Optional[Tensor] = None,
+                audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None) -> Tensor:
+        """-> last_hidden_state (B, S, H) fp32.  Exactly one of input_ids / inputs_embeds."""
+        cfg = self.config
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        ref = input_ids if input_ids is not None else inputs_embeds
+        if not ref.is_cuda:
+            raise RuntimeError("cm3p_amd runs on MI355X only: inputs must be CUDA/HIP tensors (no CPU fallback)")
+        B, S = ref.shape[0], ref.shape[1]
+        H = cfg.hidden_size
+        dev = ref.device
+
+        if input_ids is not None:
+            pad = self.embeddings.tok_embeddings.padding_idx
+            x0 = _EmbedLNFn.apply(input_ids.contiguous().view(-1), self.embeddings.tok_embeddings.weight,
+                                  self.embeddings.norm.weight, cfg.norm_eps, -1 if pad is None else pad, audio_slot, audio_rows)
+        else:
+            x0 = _LayerNormFn.apply(inputs_embeds.reshape(B * S, H), self.embeddings.norm.weight, cfg.norm_eps)
+
+        geo = _Geometry()
+        geo.B, geo.S, geo.H, geo.I, geo.nh, geo.L = B, S, H, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        geo.eps = cfg.norm_eps
+        geo.windows = [-1 if cfg.is_global_layer(i) else cfg.half_window for i in range(geo.L)]
+        geo.key_mask = None
+        if attention_mask is not None:
+            # padding term of the reference mask depends on the key only (TF:masking_utils.py:168-179)
+            geo.key_mask = (attention_mask.reshape(B, S) != 0).to(torch.uint8).contiguous()
+        if position_ids is None:
+            position_ids = torch.arange(S, device=dev).unsqueeze(0)
+        geo.per_batch_pos = position_ids.shape[0] != 1
+        if geo.per_batch_pos and position_ids.shape[0] != B:
+            raise ValueError("position_ids must be (1, S) or (B, S)")
+        pos = position_ids.contiguous().to(torch.int64)
+        tables = {}
+        for is_global, theta in ((True, cfg.global_rope_theta), (False, cfg.local_rope_theta)):
+            if any(cfg.is_global_layer(i) == is_global for i in range(geo.L)):
+                tables[is_global] = K.rope_table(pos, self._inv_freq(theta, dev))
+        geo.rope = [tables[cfg.is_global_layer(i)] for i in range(geo.L)]
+        weights = self._stack_weights()
+        geo.save = torch.is_grad_enabled() and (x0.requires_grad or any(w.requires_grad for w in weights))
+        y = _EncoderStackFn.apply(geo, x0, *weights)
+        return y.view(B, S, H)

@@ -96,7 +96,7 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, e
         out = _empty((M, N), torch.bfloat16 if epilogue == EPI_BF16 else torch.float32, a)
     ws = _empty((split_k, M, N), torch.float32, a) if split_k > 1 else None
     call("cm3p_gemm_bf16", ptr(a), ptr(b), ptr(out), ptr(resid), M, N, K, lda, ldb, N, int(a_kc), int(b_kc), epilogue, split_k,
-         ptr(ws), stream())
+         ptr(ws), stream(), tag=f"gemm_bf16_kernel<{int(a_kc)},{int(b_kc)},{epilogue}>", work=2.0 * M * N * K)
     return out
 
 
@@ -152,7 +152,9 @@ def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, 
 def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float):
     out = torch.empty((B * S, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
-    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(key_mask), B, S, nh, window, scale, stream())
+    keys = S if window < 0 else min(S, 2 * window + 1)
+    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(key_mask), B, S, nh, window, scale, stream(),
+         tag="attn_fwd_kernel" + ("<global>" if window < 0 else "<local>"), work=4.0 * B * nh * S * keys * 64)
     return out, lse
 
 
@@ -160,8 +162,9 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
              window: int, scale: float) -> Tensor:
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
+    keys = S if window < 0 else min(S, 2 * window + 1)
     call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(key_mask), B, S, nh, window, scale,
-         stream())
+         stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
     return dqkv
 
 
@@ -250,6 +253,12 @@ def first_zero_index(classes: Tensor) -> Tensor:
 def scale_exp(x: Tensor, log_scale: Tensor) -> Tensor:
     y = torch.empty_like(x)
     call("cm3p_scale_exp", ptr(x), ptr(log_scale), ptr(y), x.numel(), stream())
+    return y
+
+
+def scale_by(x: Tensor, scale: Tensor) -> Tensor:
+    y = torch.empty_like(x)
+    call("cm3p_scale_by", ptr(x), ptr(scale), ptr(y), x.numel(), stream())
     return y
 
 

@@ -1,0 +1,538 @@
+"""CM3P model classes on the MI355X kernels, behind the reference's HuggingFace surface.
+
+Drop-in for `cm3p.modeling_cm3p` on the contrastive training path (ref:cm3p/modeling_cm3p.py): same class names,
+`forward` signature (incl. `return_loss=True` and `labels`, which HF Trainer introspects), `CM3POutput` field order,
+submodule / state-dict names and Auto* registration, so `train.py` drives it unchanged.
+All arithmetic runs in libcm3p_hip.so through autograd nodes defined here and in encoder.py; there is no PyTorch-op
+fallback and inputs must live on the GPU.
+
+Scope: CM3PModel's contrastive branch with both towers and the audio front end.  The MLM / classifier
+heads (`CM3PForMaskedLM`, `CM3PForBeatmapClassification`, `has_decoder_head`) are later rows: importable, but they
+raise NotImplementedError when constructed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import torch
+from torch import nn
+from transformers import AutoModel
+from transformers.modeling_outputs import BaseModelOutput, BaseModelOutputWithPooling
+from transformers.modeling_utils import PreTrainedModel
+from transformers.utils import ModelOutput
+
+from . import kernels as K
+from .configuration_cm3p import CM3PAudioConfig, CM3PBeatmapConfig, CM3PConfig, CM3PMetadataConfig
+from .encoder import CM3PEncoder, _f32
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------- outputs
+@dataclass
+class CM3PAudioModelOutput(BaseModelOutput):
+    audio_embeds: Optional[torch.FloatTensor] = None
+
+
+@dataclass
+class CM3PBeatmapModelOutput(BaseModelOutputWithPooling):
+    beatmap_embeds: Optional[torch.FloatTensor] = None
+    audio_model_output: Optional[CM3PAudioModelOutput] = None
+
+
+@dataclass
+class CM3PMetadataModelOutput(BaseModelOutput):
+    metadata_embeds: Optional[torch.FloatTensor] = None
+
+
+@dataclass
+class CM3POutput(ModelOutput):
+    """Field ORDER is part of the interface: Trainer drops `loss` and passes the rest positionally, and the reference's
+    compute_metrics indexes [0] and [4] (ref:cm3p/modeling_cm3p.py:237-244, ref:train.py:77,101)."""
+
+    loss: Optional[torch.FloatTensor] = None
+    logits_per_beatmap: Optional[Tensor] = None
+    logits_per_metadata: Optional[Tensor] = None
+    metadata_embeds: Optional[torch.FloatTensor] = None
+    beatmap_embeds: Optional[torch.FloatTensor] = None
+    logits: Optional[torch.FloatTensor] = None
+    metadata_model_output: BaseModelOutputWithPooling = None
+    beatmap_model_output: BaseModelOutputWithPooling = None
+
+    def to_tuple(self) -> tuple[Any]:
+        nested = ("metadata_model_output", "beatmap_model_output")
+        return tuple(self[k] if k not in nested else getattr(self, k).to_tuple() for k in self.keys())
+
+
+# ----------------------------------------------------------------------------------------------- autograd nodes
+class _PoolFn(torch.autograd.Function):
+    """cls: h[:, 0]; else masked mean in fp32 (ref:cm3p/modeling_cm3p.py:385-396,631-642)."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, mask: Optional[Tensor], cls: bool):
+        Bn, S, H = h.shape
+        m = mask.contiguous().to(torch.int64) if mask is not None else None
+        pooled, count = K.pool_fwd(h.detach().contiguous(), m, Bn, S, cls)
+        ctx.pack = (m, count, Bn, S, cls)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp: Tensor):
+        m, count, Bn, S, cls = ctx.pack
+        dh = K.pool_bwd(dp.contiguous(), m, count, Bn, S, cls)
+        return dh.view(Bn, S, -1), None, None
+
+
+class _ProjectFn(torch.autograd.Function):
+    """y = x W^T in fp32: the bias-free projection heads (ref:cm3p/modeling_cm3p.py:761-762,959,971)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor):
+        x32, w32 = x.detach().contiguous(), _f32(w.detach()).contiguous()
+        R, Hin = x32.shape
+        P = w32.shape[0]
+        y = K.gemm_f32(x32, w32, R, P, Hin, (Hin, 1), (Hin, 1))
+        ctx.pack = (x32, w32, w.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x32, w32, wd = ctx.pack
+        dy = dy.contiguous()
+        R, Hin = x32.shape
+        P = w32.shape[0]
+        dx = K.gemm_f32(dy, w32, R, Hin, P, (P, 1), (1, Hin)) if ctx.needs_input_grad[0] else None  # dy W
+        dw = K.gemm_f32(dy, x32, P, Hin, R, (1, P), (1, Hin)) if ctx.needs_input_grad[1] else None  # dy^T x
+        if dw is not None and dw.dtype != wd:
+            dw = dw.to(wd)
+        return dx, dw
+
+
+class _L2NormFn(torch.autograd.Function):
+    """x / sqrt(sum x^2), no eps (ref:cm3p/modeling_cm3p.py:54-62,960,972)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        y, norm = K.l2norm_fwd(x.detach().contiguous())
+        ctx.pack = (y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        y, norm = ctx.pack
+        return K.l2norm_bwd(dy.contiguous(), y, norm)
+
+
+class _LogitsFn(torch.autograd.Function):
+    """logits = (A B^T) * exp(logit_scale) (ref:cm3p/modeling_cm3p.py:976-977).  A [M,P], B [N,P] fp32."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, log_scale: Tensor):
+        a32, b32 = a.detach().contiguous(), b.detach().contiguous()
+        s32 = _f32(log_scale.detach()).reshape(1).contiguous()
+        M, P = a32.shape
+        N = b32.shape[0]
+        raw = K.gemm_f32(a32, b32, M, N, P, (P, 1), (P, 1))
+        logits = K.scale_exp(raw, s32)
+        ctx.pack = (a32, b32, s32, logits, log_scale.dtype)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl: Tensor):
+        a32, b32, s32, logits, sd = ctx.pack
+        dl = dl.contiguous()
+        M, P = a32.shape
+        N = b32.shape[0]
+        draw = K.scale_exp(dl, s32)
+        da = K.gemm_f32(draw, b32, M, P, N, (N, 1), (1, P)) if ctx.needs_input_grad[0] else None  # draw B
+        db = K.gemm_f32(draw, a32, N, P, M, (1, N), (1, P)) if ctx.needs_input_grad[1] else None  # draw^T A
+        ds = None
+        if ctx.needs_input_grad[2]:
+            ds = K.dot_f32(dl, logits).reshape(()).to(sd)  # d/ds [raw * e^s] = logits
+        return da, db, ds
+
+
+class _CrossEntropySumFn(torch.autograd.Function):
+    """loss = sum_k coef_k * mean_rows CE_k over strided views of the given logits tensors: the pieces of cm3p_loss
+    (ref:cm3p/modeling_cm3p.py:33-51) without materialising `.t()` / `.permute().reshape()` / gathered rows.
+    spec = (tensor index, rows, cols, row_stride, col_stride, row_offset|None, target, coef)."""
+
+    @staticmethod
+    def forward(ctx, specs, *logits: Tensor):
+        ls = [l.detach().contiguous() for l in logits]
+        grads = [torch.zeros_like(l) for l in ls]
+        loss = None
+        for (ti, rows, cols, rs, cs, roff, target, coef) in specs:
+            lr = K.cross_entropy(ls[ti], rows, cols, rs, cs, target, roff, coef / rows, grads[ti])
+            loss = K.sum_f32(lr, coef / rows, out=loss, accumulate=loss is not None)
+        ctx.grads = grads
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.reshape(1).contiguous()
+        return (None, *[K.scale_by(d, g) for d in ctx.grads])
+
+
+def cm3p_loss_hip(logits_per_metadata: Tensor, metadata_variation_classes: Optional[Tensor] = None) -> Tensor:
+    """cm3p_loss on the GPU (ref:cm3p/modeling_cm3p.py:33-51), both directions from one logits tensor."""
+    L = logits_per_metadata
+    dev = L.device
+    if L.dim() == 3:
+        Bm, V, Bb = L.shape
+        if Bm != Bb:
+            raise AssertionError("metadata and beatmap batch sizes differ")
+        idx = K.first_zero_index(metadata_variation_classes.contiguous().to(torch.int64))  # (classes == 0).argmax(1)
+        rows_b = torch.arange(Bm, device=dev, dtype=torch.int64)
+        # metadata loss: rows L[b, idx[b], :]  -> row offset (b*V + idx[b]) * Bb          (integer index arithmetic only)
+        roff = (rows_b * V + idx) * Bb
+        # beatmap loss over L.permute(2,0,1).reshape(Bb, Bm*V): element (bm, m*V+v) = L[m, v, bm]; target m*V + idx[m]
+        tgt_b = rows_b * V + idx
+        specs = [(0, Bm, Bb, 0, 1, roff, rows_b, 0.5), (0, Bb, Bm * V, 1, Bb, None, tgt_b, 0.5)]
+    else:
+        Bm, Bb = L.shape
+        t = torch.arange(Bm, device=dev, dtype=torch.int64)
+        specs = [(0, Bm, Bb, Bb, 1, None, t, 0.5), (0, Bb, Bm, 1, Bb, None, t, 0.5)]
+    return _CrossEntropySumFn.apply(specs, L)
+
+
+# ----------------------------------------------------------------------------------------------- base class
+class CM3PPreTrainedModel(PreTrainedModel):
+    config_class = CM3PConfig
+    base_model_prefix = "cm3p"
+    supports_gradient_checkpointing = False
+    _supports_flash_attn_2 = True
+    _supports_flash_attn = True
+    _supports_sdpa = True
+    _supports_flex_attn = False
+
+    def _check_and_adjust_attn_implementation(self, attn_implementation, *args, **kwargs):
+        # Attention always runs in the HIP flash kernels; the configured string ("sdpa", "flash_attention_2", "eager", as
+        # `train.py` copies it from the Hydra config, ref:train.py:275) selects nothing and needs no extra package.
+        return attn_implementation if attn_implementation is not None else "sdpa"
+
+    @torch.no_grad()
+    def _init_weights(self, module):
+        """Initialisation rules of the reference wrapper (ref:cm3p/modeling_cm3p.py:262-297) and of the encoder it
+        wraps (TF:models/modernbert/modeling_modernbert.py:353-408: truncated normal, 'in' std 0.02, 'out' 0.02/sqrt(2L)).
+        HF only visits modules that own parameters, so the encoder's role-dependent stds ride on leaf tags."""
+        cfg = self.config
+        tag = getattr(module, "_cm3p_init", None)
+        if tag is not None:  # encoder leaves, tagged with their role's std by CM3PEncoder.__init__
+            std, cutoff = tag
+            nn.init.trunc_normal_(module.weight, mean=0.0, std=std, a=-cutoff * std, b=cutoff * std)
+        elif isinstance(module, nn.LayerNorm):
+            module.weight.fill_(1.0)
+        elif isinstance(module, (nn.Linear, nn.Conv1d)):
+            nn.init.normal_(module.weight, std=cfg.initializer_range)
+            if module.bias is not None:
+                module.bias.zero_()
+        elif isinstance(module, CM3PModel):
+            nn.init.normal_(module.metadata_projection.weight, std=module.metadata_embed_dim ** -0.5 * cfg.initializer_factor)
+            nn.init.normal_(module.beatmap_projection.weight, std=module.beatmap_embed_dim ** -0.5 * cfg.initializer_factor)
+            module.logit_scale.fill_(cfg.logit_scale_init_value)
+
+
+def _require_gpu(t: Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"cm3p_amd: {what} must be on the GPU; this build has no CPU path (use the reference package on CPU)")
+
+
+# ----------------------------------------------------------------------------------------------- towers
+class CM3PMetadataTransformer(nn.Module):
+    """ref:cm3p/modeling_cm3p.py:300-403."""
+
+    def __init__(self, config: CM3PMetadataConfig):
+        super().__init__()
+        self.config = config
+        self.encoder = CM3PEncoder(config)
+
+    def get_input_embeddings(self):
+        return self.encoder.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.encoder.set_input_embeddings(value)
+
+    def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None, indices=None, cu_seqlens=None,
+                max_seqlen=None, batch_size=None, seq_len=None, output_attentions=None, output_hidden_states=None,
+                output_pooler: bool = True) -> BaseModelOutputWithPooling:
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        if indices is not None or cu_seqlens is not None:
+            raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused HIP encoder")
+        _require_gpu(input_ids, "input_ids")
+        is_3d = input_ids.dim() == 3
+        B0 = input_ids.size(0)
+        ids2, am2 = input_ids, attention_mask
+        if is_3d:  # (B, V, L) -> (B*V, L), ref:cm3p/modeling_cm3p.py:351-357
+            ids2 = input_ids.reshape(-1, input_ids.size(-1))
+            am2 = attention_mask.reshape(-1, attention_mask.size(-1)) if attention_mask is not None else None
+        h = self.encoder(input_ids=ids2, attention_mask=am2)
+        pooled = _PoolFn.apply(h, am2, bool(self.config.cls_embed)) if output_pooler else None
+        if is_3d:
+            h = h.view(B0, -1, h.size(-2), h.size(-1))
+            if pooled is not None:
+                pooled = pooled.view(B0, -1, pooled.size(-1))
+        return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=pooled, hidden_states=None, attentions=None)
+
+
+class CM3PMultiModalProjector(nn.Module):
+    """Parameter container for linear_1 / linear_2 (ref:cm3p/modeling_cm3p.py:470-481)."""
+
+    def __init__(self, config: CM3PAudioConfig):
+        super().__init__()
+        if config.projector_hidden_act != "gelu":
+            raise NotImplementedError("projector_hidden_act must be 'gelu'")
+        self.linear_1 = nn.Linear(config.projector_intermediate_size, config.projector_dim, bias=False)
+        self.linear_2 = nn.Linear(config.projector_dim, config.projector_dim, bias=False)
+
+
+class CM3PAudioEncoder(nn.Module):
+    """ref:cm3p/modeling_cm3p.py:484-528: conv1d x2 + GELU -> encoder -> 4-frame concat -> projector."""
+
+    def __init__(self, config: CM3PAudioConfig):
+        super().__init__()
+        self.config = config
+        self.conv1 = nn.Conv1d(config.n_mels, config.hidden_size, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(config.hidden_size, config.hidden_size, kernel_size=3, stride=2, padding=1)
+        self.encoder = CM3PEncoder(config)
+        self.multi_modal_projector = CM3PMultiModalProjector(config)
+
+    def forward(self, input_features: Tensor, output_attentions=None, output_hidden_states=None) -> CM3PAudioModelOutput:
+        from .audio import audio_frontend, audio_projector
+
+        _require_gpu(input_features, "input_features")
+        x = audio_frontend(input_features, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)  # (B, T/2, H)
+        B, T2, _ = x.shape
+        pos = torch.arange(T2, device=x.device).unsqueeze(0).repeat(B, 1)  # explicit per-row positions, :506-507
+        h = self.encoder(inputs_embeds=x, position_ids=pos)
+        audio_embeds = audio_projector(h.reshape(-1, self.config.projector_intermediate_size),
+                                       self.multi_modal_projector.linear_1.weight, self.multi_modal_projector.linear_2.weight)
+        return CM3PAudioModelOutput(audio_embeds=audio_embeds, last_hidden_state=h, hidden_states=None, attentions=None)
+
+
+class CM3PBeatmapTransformer(nn.Module):
+    """ref:cm3p/modeling_cm3p.py:531-650."""
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__()
+        self.config = config
+        self.audio_encoder = CM3PAudioEncoder(config.audio_config)
+        self.encoder = CM3PEncoder(config)
+
+    def get_input_embeddings(self):
+        return self.encoder.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.encoder.set_input_embeddings(value)
+
+    def forward(self, input_ids: Optional[Tensor] = None, input_features: Optional[Tensor] = None,
+                attention_mask: Optional[Tensor] = None, sliding_window_mask=None, position_ids: Optional[Tensor] = None,
+                inputs_embeds: Optional[Tensor] = None, indices=None, cu_seqlens=None, max_seqlen=None, batch_size=None,
+                seq_len=None, output_attentions=None, output_hidden_states=None, output_pooler: bool = True) -> CM3PBeatmapModelOutput:
+        if indices is not None or cu_seqlens is not None:
+            raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused HIP encoder")
+        audio_out = None
+        if inputs_embeds is not None:
+            if input_features is not None:
+                raise NotImplementedError("input_features together with inputs_embeds is not supported")
+            _require_gpu(inputs_embeds, "inputs_embeds")
+            h = self.encoder(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
+        else:
+            _require_gpu(input_ids, "input_ids")
+            slot = rows = None
+            if input_features is not None:
+                audio_out = self.audio_encoder(input_features)
+                rows = audio_out.audio_embeds
+                slot, count = K.audio_slots(input_ids.contiguous().view(-1), int(self.config.audio_token_id))
+                # the reference's masked assignment raises on a count mismatch (ref:cm3p/modeling_cm3p.py:603-605)
+                n = int(count.item())
+                if n != rows.shape[0]:
+                    raise RuntimeError(f"shape mismatch: {n} audio placeholder tokens but {rows.shape[0]} audio embeddings")
+            h = self.encoder(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, audio_slot=slot,
+                             audio_rows=rows)
+        pooled = _PoolFn.apply(h, attention_mask, bool(self.config.cls_embed)) if output_pooler else None
+        return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=None, attentions=None,
+                                      audio_model_output=audio_out)
+
+
+class CM3PMetadataModel(CM3PPreTrainedModel):
+    config_class = CM3PMetadataConfig
+
+    def __init__(self, config: CM3PMetadataConfig):
+        super().__init__(config)
+        self.metadata_model = CM3PMetadataTransformer(config)
+        self.post_init()
+
+    def get_input_embeddings(self) -> nn.Module:
+        return self.metadata_model.encoder.embeddings.tok_embeddings
+
+    def set_input_embeddings(self, value):
+        self.metadata_model.encoder.embeddings.tok_embeddings = value
+
+    def forward(self, *args, **kwargs):
+        return self.metadata_model(*args, **kwargs)
+
+
+class CM3PBeatmapModel(CM3PPreTrainedModel):
+    config_class = CM3PBeatmapConfig
+    main_input_name = "input_ids"
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__(config)
+        self.beatmap_model = CM3PBeatmapTransformer(config)
+        self.post_init()
+
+    def get_input_embeddings(self) -> nn.Module:
+        return self.beatmap_model.encoder.embeddings.tok_embeddings
+
+    def set_input_embeddings(self, value):
+        self.beatmap_model.encoder.embeddings.tok_embeddings = value
+
+    def forward(self, *args, **kwargs):
+        return self.beatmap_model(*args, **kwargs)
+
+
+# ----------------------------------------------------------------------------------------------- the dual tower
+class CM3PModel(CM3PPreTrainedModel):
+    config_class = CM3PConfig
+
+    def __init__(self, config: CM3PConfig):
+        super().__init__(config)
+        if not isinstance(config.metadata_config, CM3PMetadataConfig):
+            raise TypeError(f"config.metadata_config is expected to be of type CM3PMetadataConfig but is of type {type(config.metadata_config)}.")
+        if not isinstance(config.beatmap_config, CM3PBeatmapConfig):
+            raise TypeError(f"config.beatmap_config is expected to be of type CM3PBeatmapConfig but is of type {type(config.beatmap_config)}.")
+        if config.has_decoder_head:
+            raise NotImplementedError("has_decoder_head (MLM head + 0.5*mlm_loss) is a later row of SURVEY.md §8(f); not in this build")
+        self.projection_dim = config.projection_dim
+        self.metadata_embed_dim = config.metadata_config.hidden_size
+        self.beatmap_embed_dim = config.beatmap_config.hidden_size
+        self.metadata_model = CM3PMetadataTransformer(config.metadata_config)
+        self.beatmap_model = CM3PBeatmapTransformer(config.beatmap_config)
+        self.beatmap_projection = nn.Linear(self.beatmap_embed_dim, self.projection_dim, bias=False)
+        self.metadata_projection = nn.Linear(self.metadata_embed_dim, self.projection_dim, bias=False)
+        self.logit_scale = nn.Parameter(torch.tensor(float(config.logit_scale_init_value)))
+        # Opt-in: in-batch negatives across all ranks of the default process group (new behaviour).
+        self.gather_negatives = False
+        self.post_init()
+
+    def get_metadata_features(self, input_ids=None, output_attentions=None, output_hidden_states=None) -> Tensor:
+        out = self.metadata_model(input_ids=input_ids)
+        p = out.pooler_output
+        return _ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight).view(*p.shape[:-1], -1)
+
+    def get_beatmap_features(self, input_ids=None, input_features=None, attention_mask=None, position_ids=None, inputs_embeds=None,
+                             output_attentions=None, output_hidden_states=None) -> Tensor:
+        out = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                 position_ids=position_ids, inputs_embeds=inputs_embeds)
+        return _ProjectFn.apply(out.pooler_output, self.beatmap_projection.weight)
+
+    def forward(
+        self,
+        input_ids: Optional[torch.LongTensor] = None,
+        input_features: Optional[torch.FloatTensor] = None,
+        metadata_ids: Optional[torch.LongTensor] = None,
+        attention_mask: Optional[Tensor] = None,
+        metadata_attention_mask: Optional[Tensor] = None,
+        position_ids: Optional[torch.LongTensor] = None,
+        inputs_embeds: Optional[torch.FloatTensor] = None,
+        metadata_variation_classes: Optional[torch.LongTensor] = None,
+        labels: Optional[Tensor] = None,
+        indices: Optional[Tensor] = None,
+        cu_seqlens: Optional[Tensor] = None,
+        max_seqlen: Optional[int] = None,
+        batch_size: Optional[int] = None,
+        seq_len: Optional[int] = None,
+        return_loss: Optional[bool] = True,
+        output_attentions: Optional[bool] = None,
+        output_hidden_states: Optional[bool] = None,
+        output_logits: Optional[bool] = None,
+        **kwargs,
+    ) -> CM3POutput:
+        """Contrastive forward (ref:cm3p/modeling_cm3p.py:849-1012).  Padded batches only: whatever `attn_implementation`
+        says, attention runs in the HIP flash kernels and no host-side unpadding is needed."""
+        output_logits = output_logits if output_logits is not None else self.config.has_decoder_head
+        if metadata_ids is not None and metadata_ids.dim() == 3 and return_loss and metadata_variation_classes is None:
+            raise ValueError("When providing multiple metadata variations, metadata_variation_classes must be provided in order to compute loss correctly.")
+        if output_logits and not self.config.has_decoder_head:
+            raise ValueError("Cannot return logits when the model is not configured with a decoder head.")
+
+        beatmap_embeds = beatmap_outputs = metadata_embeds = metadata_outputs = None
+        logits_per_beatmap = logits_per_metadata = None
+        loss = 0 if return_loss else None
+
+        if input_ids is not None:
+            beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                                 position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
+                                                 cu_seqlens=cu_seqlens, output_attentions=output_attentions,
+                                                 output_hidden_states=output_hidden_states)
+            beatmap_embeds = _L2NormFn.apply(_ProjectFn.apply(beatmap_outputs.pooler_output, self.beatmap_projection.weight))
+
+        if metadata_ids is not None:
+            metadata_outputs = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
+                                                   output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+            p = metadata_outputs.pooler_output
+            me = _L2NormFn.apply(_ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight))
+            metadata_embeds = me.view(*p.shape[:-1], -1)
+
+        if metadata_embeds is not None and beatmap_embeds is not None:
+            me2 = metadata_embeds.reshape(-1, metadata_embeds.size(-1))
+            if self.gather_negatives and metadata_embeds.dim() == 2:
+                from .dist import gathered_contrastive
+
+                logits_per_metadata, logits_per_beatmap, gl = gathered_contrastive(me2, beatmap_embeds, self.logit_scale)
+                if return_loss:
+                    loss = gl
+            else:
+                lpm = _LogitsFn.apply(me2, beatmap_embeds, self.logit_scale)
+                if metadata_embeds.dim() == 3:
+                    logits_per_metadata = lpm.view(metadata_embeds.size(0), metadata_embeds.size(1), -1)
+                    logits_per_beatmap = logits_per_metadata.permute(2, 0, 1)
+                else:
+                    logits_per_metadata = lpm
+                    logits_per_beatmap = lpm.t()
+                if return_loss:
+                    loss = cm3p_loss_hip(logits_per_metadata, metadata_variation_classes)
+
+        return CM3POutput(loss=loss, logits_per_beatmap=logits_per_beatmap, logits_per_metadata=logits_per_metadata,
+                          metadata_embeds=metadata_embeds, beatmap_embeds=beatmap_embeds, logits=None,
+                          metadata_model_output=metadata_outputs, beatmap_model_output=beatmap_outputs)
+
+
+# ----------------------------------------------------------------------------------------------- later rows (importable)
+def _later_row(name: str, row: str):
+    class _NotInThisBuild(CM3PPreTrainedModel):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} is outside this build's scope ({row}); use the reference implementation for it")
+
+    _NotInThisBuild.__name__ = _NotInThisBuild.__qualname__ = name
+    return _NotInThisBuild
+
+
+CM3PForMaskedLM = _later_row("CM3PForMaskedLM", "SURVEY.md §8(f) rank 2: MLM head")
+CM3PForBeatmapClassification = _later_row("CM3PForBeatmapClassification", "SURVEY.md §2: classifier variant")
+CM3PMetadataModelWithProjection = _later_row("CM3PMetadataModelWithProjection", "SURVEY.md §2: projection-only variant")
+CM3PBeatmapModelWithProjection = _later_row("CM3PBeatmapModelWithProjection", "SURVEY.md §2: projection-only variant")
+
+
+def _register():
+    for cfg, cls in ((CM3PMetadataConfig, CM3PMetadataModel), (CM3PBeatmapConfig, CM3PBeatmapModel), (CM3PConfig, CM3PModel)):
+        try:
+            AutoModel.register(cfg, cls)
+        except ValueError:
+            pass
+
+
+_register()
+
+__all__ = [
+    "CM3PModel", "CM3PPreTrainedModel", "CM3PMetadataModel", "CM3PBeatmapModel", "CM3PMetadataTransformer",
+    "CM3PBeatmapTransformer", "CM3PAudioEncoder", "CM3POutput", "CM3PForMaskedLM", "CM3PForBeatmapClassification",
+    "CM3PMetadataModelWithProjection", "CM3PBeatmapModelWithProjection", "cm3p_loss_hip",
+]

@@ -170,6 +170,8 @@ int cm3p_cross_entropy(const float* logits, int rows, int cols, int64_t row_stri
                        void* stream);
 /* y = x * exp(*log_scale): `logits * self.logit_scale.exp()` (ref:cm3p/modeling_cm3p.py:977) without a host read. */
 int cm3p_scale_exp(const float* x, const float* log_scale, float* y, int64_t n, void* stream);
+/* y = x * (*scale), scale a device scalar: chain rule through a scalar loss without a host read. */
+int cm3p_scale_by(const float* x, const float* scale, float* y, int64_t n, void* stream);
 /* out[0] = sum a[i]*b[i] (fixed order): d logit_scale = <dlogits, logits>. */
 int cm3p_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* out[0] (+)= scale * sum x[i] (fixed order): the mean over rows inside cross_entropy and the /2 of cm3p_loss. */
