@@ -41,6 +41,11 @@ SIGNATURES = {
     "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],
     "cm3p_gelu_fwd": [_P, _P, _L, _P],
     "cm3p_gelu_bwd": [_P, _P, _P, _L, _P],
+    "cm3p_im2col_k3": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "cm3p_col2im_k3": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "cm3p_bias_gelu_fwd": [_P, _P, _P, _P, _L, _I, _P],
+    "cm3p_bias_gelu_bwd_blocks": [_L],
+    "cm3p_bias_gelu_bwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "cm3p_pool_chunks": [_I],
     "cm3p_pool_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "cm3p_pool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -194,6 +194,37 @@ def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
     return dx
 
 
+# ------------------------------------------------------------------------------------------------ audio front end
+def im2col_k3(x: Tensor, token_major: bool, B: int, C: int, T_in: int, stride: int):
+    T_out = (T_in - 1) // stride + 1
+    p = torch.empty((B * T_out, C * 3), dtype=torch.bfloat16, device=x.device)
+    call("cm3p_im2col_k3", ptr(x), int(token_major), ptr(p), B, C, T_in, T_out, stride, stream())
+    return p, T_out
+
+
+def col2im_k3(dp: Tensor, B: int, C: int, T_in: int, T_out: int, stride: int) -> Tensor:
+    dx = torch.empty((B, T_in, C), dtype=torch.bfloat16, device=dp.device)
+    call("cm3p_col2im_k3", ptr(dp), ptr(dx), B, C, T_in, T_out, stride, stream())
+    return dx
+
+
+def bias_gelu_fwd(z: Tensor, bias: Tensor, want_bf16: bool, want_f32: bool):
+    R, C = z.shape
+    a16 = torch.empty((R, C), dtype=torch.bfloat16, device=z.device) if want_bf16 else None
+    a32 = torch.empty((R, C), dtype=torch.float32, device=z.device) if want_f32 else None
+    call("cm3p_bias_gelu_fwd", ptr(z), ptr(bias), ptr(a16), ptr(a32), R, C, stream())
+    return a16, a32
+
+
+def bias_gelu_bwd(da: Tensor, z: Tensor, bias: Tensor):
+    R, C = z.shape
+    dz = torch.empty((R, C), dtype=torch.bfloat16, device=z.device)
+    part = torch.empty((query("cm3p_bias_gelu_bwd_blocks", R), C), dtype=torch.float32, device=z.device)
+    db = torch.empty((C,), dtype=torch.float32, device=z.device)
+    call("cm3p_bias_gelu_bwd", ptr(da), dt(da), ptr(z), ptr(bias), ptr(dz), ptr(part), ptr(db), R, C, stream())
+    return dz, db
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 def pool_fwd(h: Tensor, mask: Optional[Tensor], Bn: int, S: int, cls: bool):
     H = h.shape[-1]

@@ -140,6 +140,24 @@ int cm3p_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int cm3p_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Audio front end: Conv1d(kernel 3, padding 1, stride 1|2) as im2col + cm3p_gemm_bf16, then bias + GELU
+ * (CM3PAudioEncoder.forward, ref:cm3p/modeling_cm3p.py:488-489,501-504).
+ * cm3p_im2col_k3: x is [B, C, T_in] fp32 (x_token_major = 0, the mel input) or [B, T_in, C] bf16 (x_token_major = 1);
+ *   patches [B*T_out, C*3] bf16 with column c*3 + kk = x[b, c, t*stride + kk - 1] (zero outside), matching the
+ *   Conv1d weight [C_out, C, 3] viewed as [C_out, C*3].  T_out = (T_in - 1) / stride + 1.
+ * cm3p_col2im_k3: the transpose for token-major inputs: dx [B, T_in, C] bf16 from dpatches.
+ * cm3p_bias_gelu_fwd: a = gelu_erf(z + bias), z fp32 [R, C]; writes bf16 and/or fp32.
+ * cm3p_bias_gelu_bwd: dz = da * gelu'(z + bias) (bf16) and dbias[C] = column sums of dz; db_partial is a
+ *   [cm3p_bias_gelu_bwd_blocks(R), C] fp32 workspace.
+ */
+int cm3p_im2col_k3(const void* x, int x_token_major, void* patches, int B, int C, int T_in, int T_out, int stride, void* stream);
+int cm3p_col2im_k3(const void* dpatches, void* dx, int B, int C, int T_in, int T_out, int stride, void* stream);
+int cm3p_bias_gelu_fwd(const float* z, const float* bias, void* a_bf16, float* a_f32, int64_t R, int C, void* stream);
+int cm3p_bias_gelu_bwd_blocks(int64_t R);
+int cm3p_bias_gelu_bwd(const void* da, int da_dtype, const float* z, const float* bias, void* dz_bf16, float* db_partial,
+                       float* dbias, int64_t R, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Pooling of the last hidden state (ref:cm3p/modeling_cm3p.py:385-396, 631-642).
  *   cls != 0: pooled[b] = h[b, 0];  else pooled[b] = sum_s h[b,s]*m[b,s] / max(sum_s m[b,s], 1e-9)  (m all ones if NULL).
  * h: [Bn, S, H] fp32, mask: [Bn, S] int64 or NULL, pooled: [Bn, H] fp32.  partial: fp32 workspace

@@ -1,0 +1,87 @@
+"""world_size-2 gloo test of the cross-rank negatives exchange, on CPU.
+
+The product's collective plumbing (cm3p_amd.dist.AllGatherEmbeds / gather_pair) is device agnostic; the arithmetic around
+it in this test is the oracle's.  Invariant: with DDP-style gradient AVERAGING, the parameter gradients on every rank
+equal the gradients of the reference single-process loss on the concatenated N*b batch, and the mean of the per-rank
+losses equals that loss (tolerance 1e-6, fp32).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _towers(params, xm, xb):
+    """Stand-in towers: one linear map per modality, then L2 normalisation as the reference does."""
+    from oracle import cm3p_oracle as O
+
+    return O.l2_normalize(xm @ params["wm"].t()), O.l2_normalize(xb @ params["wb"].t())
+
+
+def _make(world, b, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    params = {"wm": torch.randn(16, 12, generator=g), "wb": torch.randn(16, 20, generator=g), "s": torch.tensor(1.3)}
+    xm = torch.randn(world * b, 12, generator=g)
+    xb = torch.randn(world * b, 20, generator=g)
+    return params, xm, xb
+
+
+def _worker(rank, world, port, b, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cm3p_amd.dist import gather_pair
+
+        params, xm, xb = _make(world, b)
+        params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        sl = slice(rank * b, (rank + 1) * b)
+        me, be = _towers(params, xm[sl], xb[sl])
+        m_all, b_all = gather_pair(me, be)
+        assert m_all.shape == (world * b, 16)
+        scale = params["s"].exp()
+        target = torch.arange(rank * b, (rank + 1) * b)
+        loss = 0.5 * (F.cross_entropy(me @ b_all.t() * scale, target) + F.cross_entropy(be @ m_all.t() * scale, target))
+        loss.backward()
+        grads = {}
+        for k, p in params.items():
+            gavg = p.grad.clone()
+            dist.all_reduce(gavg)  # what DDP does: sum, then divide by world size
+            grads[k] = gavg / world
+        lmean = loss.detach().clone()
+        dist.all_reduce(lmean)
+        out[rank] = (lmean / world, grads, m_all.detach(), b_all.detach())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b", [(2, 3), (2, 1)])
+def test_gathered_loss_and_grads_equal_single_process_reference(world, b):
+    from oracle import cm3p_oracle as O
+
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, b, out), nprocs=world, join=True)
+
+    params, xm, xb = _make(world, b)
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    me, be = _towers(params, xm, xb)
+    ref_loss = O.cm3p_loss(me @ be.t() * params["s"].exp())  # ref:cm3p/modeling_cm3p.py:33-51,976-977 on the global batch
+    ref_loss.backward()
+    for rank in range(world):
+        lmean, grads, m_all, b_all = out[rank]
+        assert torch.allclose(m_all, me.detach(), atol=1e-7) and torch.allclose(b_all, be.detach(), atol=1e-7)  # rank order
+        assert abs(lmean.item() - ref_loss.item()) <= 1e-6
+        for k, p in params.items():
+            assert torch.allclose(grads[k], p.grad, atol=1e-6, rtol=1e-5), (rank, k, (grads[k] - p.grad).abs().max())

@@ -346,3 +346,28 @@ def test_head_kernels(K):
     K.sum_f32(lc, 0.5 / 12, out=got_loss, accumulate=True)
     _assert_close(got_loss, loss.detach().reshape(1), 1e-6, 1e-6, "clip loss")
     _assert_close(d, Lr.grad, 1e-7, 1e-5, "clip dlogits")
+
+
+# ------------------------------------------------------------------------------------------------ audio front end
+def test_audio_conv_frontend_matches_conv1d(K):
+    """im2col + GEMM + bias/GELU against F.conv1d on bf16-rounded weights (tolerance: bf16 activations, 1e-2 relative)."""
+    from cm3p_amd.audio import audio_frontend
+
+    g = torch.Generator().manual_seed(31)
+    B, n_mels, T, C = 2, 16, 96, 64
+    x = torch.randn(B, n_mels, T, generator=g)
+    w1 = (torch.randn(C, n_mels, 3, generator=g) * 0.2).requires_grad_(True)
+    b1 = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(C, C, 3, generator=g) * 0.1).requires_grad_(True)
+    b2 = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    y = F.gelu(F.conv1d(F.gelu(F.conv1d(x, w1, b1, padding=1)), w2, b2, stride=2, padding=1)).permute(0, 2, 1)
+    dy = torch.randn(B, T // 2, C, generator=g)
+    y.backward(dy)
+    ps = [p.detach().clone().to(DEV).requires_grad_(True) for p in (w1, b1, w2, b2)]
+    got = audio_frontend(x.to(DEV), *ps)
+    assert got.shape == (B, T // 2, C) and got.dtype == torch.float32
+    got.backward(dy.to(DEV))
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
+    assert rel(got.detach(), y.detach()) <= 1e-2
+    for p, r, nm in zip(ps, (w1, b1, w2, b2), ("w1", "b1", "w2", "b2")):
+        assert rel(p.grad, r.grad) <= 2e-2, (nm, rel(p.grad, r.grad))
