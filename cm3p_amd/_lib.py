@@ -31,6 +31,7 @@ SIGNATURES = {
     "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _P],
     "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
+    "cm3p_gemm_wgrad_splits": [_L, _L, _L],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
     "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],

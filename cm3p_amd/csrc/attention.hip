@@ -18,6 +18,8 @@
 //            dV^T += dO^T P and dK^T += Q^T dS consume the accumulators directly as B operands.
 // LDS images (128-byte rows): "R" for ds_read_b128 row fragments (16-byte chunk index XOR (row>>1)&7) and "T" for
 // transposed reads (32-byte segment index XOR 2*((row>>1)&1)); both are bank-conflict free for these access shapes.
+#include <limits.h>
+
 #include "common.h"
 
 namespace {
@@ -95,10 +97,10 @@ __device__ __forceinline__ float reg_max16(const f32x16& a) {
     return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
-// visibility of keys (tile key0 + 32*blk + rows of the accumulator) for this lane's query `qrow`
-// maskb: 64 bytes of key validity for the tile in LDS.  Sets invisible scores to -inf.
-__device__ __forceinline__ void mask_scores_keyrows(f32x16& s, const uint8_t* maskb, int blk, int key0, int qrow, int window,
-                                                    int hh) {
+// Visibility of keys (tile key0 + 32*blk + accumulator rows) for this lane's query: invisible scores become -inf.
+// Branch-free: [lo, hi] is the lane's window in absolute key positions (whole axis for global layers), maskb holds one
+// validity byte per key of the tile (padding and keys >= S are 0).
+__device__ __forceinline__ void mask_scores_keyrows(f32x16& s, const uint8_t* maskb, int blk, int key0, int lo, int hi, int hh) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int kl = 32 * blk + 8 * g + 4 * hh;
@@ -106,18 +108,23 @@ __device__ __forceinline__ void mask_scores_keyrows(f32x16& s, const uint8_t* ma
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = key0 + kl + r;
-            const int dist = qrow > key ? qrow - key : key - qrow;
-            const bool ok = ((mb >> (8 * r)) & 0xffu) != 0u && (window < 0 || dist <= window);
-            if (!ok) s[4 * g + r] = kNegInf;
+            const bool ok = (((mb >> (8 * r)) & 0xffu) != 0u) & (key >= lo) & (key <= hi);
+            s[4 * g + r] = ok ? s[4 * g + r] : kNegInf;
         }
     }
+}
+
+// true when a 64-key tile needs no masking for any query of a 32-row wave block [q0, q0+31]:
+// every key valid (flag computed when the tile's mask bytes were staged) and the tile inside every row's window
+__device__ __forceinline__ bool tile_unmasked(int all_valid, int key0, int q0, int window) {
+    return all_valid && (window < 0 || (key0 >= q0 + 31 - window && key0 + 63 <= q0 + window));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward: one workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 64 keys, double buffered.
 // LDS per stage: K image R (8 KiB) + V image T (8 KiB) + 64 mask bytes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kFwdStage = 8192 + 8192 + 64;
+constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask bytes, all-valid flag
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                           float* __restrict__ lse, const uint8_t* __restrict__ kmask, int S,
@@ -131,9 +138,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
-    const bool masked = (kmask != nullptr) || window >= 0 || (S % 64 != 0);
-
     const int qrow = q0 + (lane & 31);
+    const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
     const int qrow_c = qrow < S ? qrow : S - 1;
     bf16x8 qf[4];
 #pragma unroll
@@ -171,7 +177,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         char* st = smem + stage * kFwdStage;
         lstore64_R(st, kr, tid);
         lstore64_T(st + 8192, vr, tid);
-        if (tid < 64) reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
+        if (tid < 64) {
+            reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
+            const unsigned long long valid = __ballot(mreg != 0);
+            if (tid == 0) *reinterpret_cast<int*>(st + 16448) = (valid == ~0ull) ? 1 : 0;
+        }
     };
 
     gload(t_lo);
@@ -194,10 +204,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int s = 0; s < 4; ++s) sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
             }
-            if (masked) {
+            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 16448), key0, q0, window)) {
                 const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
-                mask_scores_keyrows(sacc[0], mb, 0, key0, qrow, window, hh);
-                mask_scores_keyrows(sacc[1], mb, 1, key0, qrow, window, hh);
+                mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
+                mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
             }
             float mt = fmaxf(reg_max16(sacc[0]), reg_max16(sacc[1]));
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // dQ: same geometry as the forward.  LDS per stage: K image R + K image T + V image R + mask bytes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDqStage = 3 * 8192 + 64;
+constexpr int kDqStage = 3 * 8192 + 64 + 16;
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 
     const int qrow = q0 + (lane & 31);
     const int qrow_c = qrow < S ? qrow : S - 1;
+    const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -341,7 +352,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         lstore64_R(st, kr, tid);
         lstore64_T(st + 8192, kr, tid);
         lstore64_R(st + 16384, vr, tid);
-        if (tid < 64) reinterpret_cast<uint8_t*>(st + 24576)[tid] = mreg;
+        if (tid < 64) {
+            reinterpret_cast<uint8_t*>(st + 24576)[tid] = mreg;
+            const unsigned long long valid = __ballot(mreg != 0);
+            if (tid == 0) *reinterpret_cast<int*>(st + 24640) = (valid == ~0ull) ? 1 : 0;
+        }
     };
 
     gload(t_lo);
@@ -366,9 +381,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                     dp[blk] = mfma32(frag_R(st + 16384, 32 * blk, s, lane), dof[s], dp[blk]);
                 }
             }
-            const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 24576);
-            mask_scores_keyrows(sacc[0], mb, 0, key0, qrow, window, hh);
-            mask_scores_keyrows(sacc[1], mb, 1, key0, qrow, window, hh);
+            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 24640), key0, q0, window)) {
+                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 24576);
+                mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
+                mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
+            }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -434,6 +451,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
     }
     const bool key_ok = krow < S && (kmask ? kmask[(int64_t)b * S + krow] != 0 : true);
+    const bool keys_all_ok = __all(key_ok);
+    const int lo = window < 0 ? INT_MIN : krow - window, hi = window < 0 ? INT_MAX : krow + window;
     const float c = scale * kLog2e;
     const float inv_scale = 1.0f / scale;
 
@@ -504,18 +523,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                     sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);           // S - lse/scale, rows q, col key
                     dp = mfma32(frag_R(st + 16384, 32 * qb, s, lane), vf[s], dp);       // dP - delta
                 }
+                // every (query, key) pair of this 32 x 32 block visible?  (queries past S carry -inf and give p = 0 anyway)
+                const int qb0 = qt0 + 32 * qb;
+                const bool plain = keys_all_ok && (window < 0 || (qb0 >= k0 + 31 - window && qb0 + 31 <= k0 + window));
+                if (plain) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * g + r;
-                        const int q = qt0 + 32 * qb + 8 * g + 4 * hh + r;
-                        const int dist = q > krow ? q - krow : krow - q;
-                        const bool ok = key_ok && (window < 0 || dist <= window);
-                        const float p = ok ? __builtin_amdgcn_exp2f(sacc[i] * c) : 0.f;
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[i] * c);
                         sacc[i] = p;
                         dp[i] = p * dp[i] * scale;  // dS
                     }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 4 * g + r;
+                            const int q = qb0 + 8 * g + 4 * hh + r;
+                            const bool ok = key_ok & (q >= lo) & (q <= hi);
+                            const float p = ok ? __builtin_amdgcn_exp2f(sacc[i] * c) : 0.f;
+                            sacc[i] = p;
+                            dp[i] = p * dp[i] * scale;  // dS
+                        }
+                }
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     const bf16x8 pf = acc_to_frag(sacc, sp);

@@ -219,7 +219,30 @@ int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int
 
 }  // namespace
 
+// gemm256.hip: the 256 x 256 LDS-DMA kernel for the big shapes
+int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
+                          int64_t c_split_stride, hipStream_t s);
+
+static inline int64_t tiles_of(int64_t M, int64_t N, int t) { return ((M + t - 1) / t) * ((N + t - 1) / t); }
+
 extern "C" {
+
+int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {
+    // dW = dy^T x: few output tiles, contraction over all tokens.  Aim at ~2 workgroups per CU.
+    const int64_t t256 = tiles_of(M, N, 256);
+    if (K % 64 == 0 && K >= 8192) {
+        int64_t s = (512 + t256 - 1) / t256;
+        if (s > K / 2048) s = K / 2048;
+        if (s < 1) s = 1;
+        if (t256 * s >= 200) return (int)s;
+    }
+    const int64_t t128 = tiles_of(M, N, 128);
+    if (t128 >= 512 || K <= 1024) return 1;
+    int64_t s = (1024 + t128 - 1) / t128;
+    if (s > K / 512) s = K / 512;
+    return (int)(s < 1 ? 1 : s);
+}
 
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream) {
@@ -244,7 +267,9 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
         split_stride = M * N;
     }
     int rc;
-    if (a_kc && b_kc) rc = launch<true, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
+    const bool big = (K % 64 == 0) && (kchunk % 64 == 0) && tiles_of(M, N, 256) * split_k >= 200;
+    if (big) rc = cm3p_gemm256_dispatch(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s);
+    else if (a_kc && b_kc) rc = launch<true, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (a_kc) rc = launch<true, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (b_kc) rc = launch<false, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else rc = launch<false, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);

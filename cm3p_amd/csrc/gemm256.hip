@@ -1,0 +1,211 @@
+// Large-tile bf16 MFMA GEMM: 256 x 256 x 64 per 512-thread workgroup, operands streamed global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging, no ds_write), double-buffered, one barrier per k-step.
+//
+// Same contract as gemm.hip (C[m,n] = sum_k A(m,k) B(n,k) (+R); a_kc / b_kc layouts; epilogues; split-K) for the
+// shapes that dominate the step: K a multiple of 64.  The 128 x 128 kernel in gemm.hip keeps every other shape.
+// Why a second kernel: at 128 x 128 a workgroup moves 1/64 byte per flop from L2 - more than the chip's L2 can feed at
+// MFMA speed; 256 x 256 halves that, and LDS-DMA frees ~64 VGPRs and all staging instructions.
+//
+// LDS image per stage (64 KiB): A then B, 32 KiB each.
+//   k-contiguous operand: [256 rows][64 k] bf16, 128-byte rows, 16-byte chunk index XOR (row & 7).
+//   k-strided operand:    [64 k][256 idx] bf16, 512-byte rows, 32-byte segment index XOR f(k), f(k) = (k&3) | ((k>>3)&1)<<2.
+// LDS-DMA writes lane-linearly (wave base + 16 * lane), so the swizzle is applied to each lane's SOURCE address and
+// again when fragments are read (both sides or neither).
+// 8 waves as 2 (m) x 4 (n); each wave owns 128 x 64 of C = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator VGPRs).
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kOperandBytes = TM * TK * 2;  // 32 KiB
+constexpr int kStage = 2 * kOperandBytes;   // 64 KiB
+
+__device__ __forceinline__ int kc_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+__device__ __forceinline__ int ksf(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int ks_off(int k, int idx) { return k * 512 + (((idx >> 4) ^ ksf(k)) << 5) + ((idx & 15) << 1); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Per-thread source pointers for the 4 one-KiB pieces this wave stages per operand per k-tile.
+template <bool KC>
+struct Stager {
+    const uint16_t* src[4];
+    int64_t kstep;
+
+    __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int64_t idx0, int64_t extent, int64_t kbeg, int wid,
+                                         int lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wid * 4 + i;  // piece index 0..31 inside the operand image
+            if constexpr (KC) {
+                const int r = q * 8 + (lane >> 3);            // row inside the tile
+                const int c = (lane & 7) ^ (r & 7);           // which 16-byte chunk of the row lands at this lane's slot
+                int64_t row = idx0 + r;
+                if (row > extent - 1) row = extent - 1;       // clamp: rows past the edge are never stored
+                src[i] = base + row * ld + kbeg + c * 8;
+            } else {
+                const int k = q * 2 + (lane >> 5);
+                const int p = lane & 31;
+                const int seg = (p >> 1) ^ ksf(k);
+                int64_t col = idx0 + (seg * 2 + (p & 1)) * 8;
+                if (col > extent - 8) col = extent - 8;       // clamp (extent % 8 == 0)
+                src[i] = base + (kbeg + k) * ld + col;
+            }
+        }
+        kstep = KC ? TK : TK * ld;
+    }
+    __device__ __forceinline__ void issue(char* image, int wid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(src[i], image + (wid * 4 + i) * 1024);
+            src[i] += kstep;
+        }
+    }
+};
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag(const char* image, int idx0, int kk, int lane) {
+    if constexpr (KC) {
+        const int r = idx0 + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(image + kc_off(r, kk * 4 + (lane >> 4)));
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int k = kk * 32 + 8 * g + q;
+        const bf16x4 lo = lds_read_tr16(image + ks_off(k, idx0 + 4 * p));
+        const bf16x4 hi = lds_read_tr16(image + ks_off(k + 4, idx0 + 4 * p));
+        return cat_bf16x4(lo, hi);
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                         void* __restrict__ Cv, const float* R, int64_t M, int64_t N, int64_t K,
+                                                         int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int64_t kchunk,
+                                                         int64_t c_split_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int tm = swz / tiles_n, tn = swz % tiles_n;
+    const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+
+    const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+    const int64_t kend = min(K, kbeg + kchunk);
+    const int nk = (int)((kend - kbeg) / TK);  // K % 64 == 0 on this path
+
+    Stager<A_KC> sa;
+    Stager<B_KC> sb;
+    sa.init(A, lda, m0, M, kbeg, wid, lane);
+    sb.init(B, ldb, n0, N, kbeg, wid, lane);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        sa.issue(smem, wid);
+        sb.issue(smem + kOperandBytes, wid);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * kStage;
+        char* nxt = smem + ((kt + 1) & 1) * kStage;
+        if (kt + 1 < nk) {
+            sa.issue(nxt, wid);
+            sb.issue(nxt + kOperandBytes, wid);
+        }
+        const char* ia = cur;
+        const char* ib = cur + kOperandBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for the next stage has landed
+        __syncthreads();                                   // everyone's has, and everyone is done reading `cur`
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            if constexpr (EPI == CM3P_EPI_BF16) {
+                uint16_t* C = static_cast<uint16_t*>(Cv);
+                *reinterpret_cast<uint2*>(C + m * ldc + n) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            } else {
+                float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
+                if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
+                *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+            }
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+              int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s) {
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
+    const dim3 grid(tiles_m * tiles_n, 1, splits);
+    const size_t lds = 2 * kStage;
+#define CM3P_G256(E)                                                                                                     \
+    {                                                                                                                    \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute((const void*)gemm256_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess)                                                             \
+                return CM3P_ERR_LAUNCH;                                                                                  \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride); \
+    }
+    switch (epi) {
+        case CM3P_EPI_BF16: CM3P_G256(CM3P_EPI_BF16) break;
+        case CM3P_EPI_F32: CM3P_G256(CM3P_EPI_F32) break;
+        case CM3P_EPI_F32_RESID: CM3P_G256(CM3P_EPI_F32_RESID) break;
+        default: return CM3P_ERR_INVALID;
+    }
+#undef CM3P_G256
+    return CM3P_OK;
+}
+
+}  // namespace
+
+// Internal entry used by cm3p_gemm_bf16 (gemm.hip) when the shape qualifies; not part of the public header.
+int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
+                          int64_t c_split_stride, hipStream_t s) {
+    const uint16_t* a = static_cast<const uint16_t*>(A);
+    const uint16_t* b = static_cast<const uint16_t*>(B);
+    if (a_kc && b_kc) return launch256<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
+    if (a_kc) return launch256<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
+    if (b_kc) return launch256<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
+    return launch256<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
+}

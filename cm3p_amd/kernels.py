@@ -82,10 +82,7 @@ def audio_slots(ids: Tensor, audio_token_id: int):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def _wgrad_splits(M: int, N: int, K: int) -> int:
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 512 or K <= 1024:
-        return 1
-    return max(1, min((1024 + tiles - 1) // tiles, K // 512))
+    return query("cm3p_gemm_wgrad_splits", M, N, K)
 
 
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, epilogue: int,

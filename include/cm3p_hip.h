@@ -92,6 +92,9 @@ int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int3
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
 
+/* Host-only: the split_k the library recommends for a weight-gradient GEMM of this shape (sizes the workspace). */
+int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K);
+
 /* fp32 -> bf16 cast of n elements (n % 4 == 0): the autocast weight / activation cast in front of a bf16 linear. */
 int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 /* y_f32 (and y_bf16 if not NULL) = a_f32 + b (b fp32 or bf16); n % 4 == 0.  Residual-gradient join for layer 0,

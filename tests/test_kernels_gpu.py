@@ -78,6 +78,31 @@ def test_gemm_wgrad_layout(K, T, N, K_, split):
     _assert_close(got, dy.t() @ x, 0, 0, "wgrad")
 
 
+@pytest.mark.parametrize("M,N,K_", [(8192, 2304, 768), (8200, 2312, 128), (16384, 768, 1152)])
+def test_gemm256_forward_and_dgrad_layout(K, M, N, K_):
+    """Shapes large enough to take the 256 x 256 LDS-DMA kernel (incl. ragged M / N edges): exact integer check."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randint(-3, 4, (M, K_), generator=g).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g).float()
+    want = x @ w.t()
+    _assert_close(K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 1), want, 0, 0, "fwd256 f32")
+    _assert_close(K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 0), want.to(torch.bfloat16), 0, 0, "fwd256 bf16")
+    r = torch.randn(M, N, generator=g)
+    _assert_close(K.gemm(_bf(x).to(DEV), _bf(w).to(DEV), M, N, K_, True, True, 2, resid=r.to(DEV)), want + r, 1e-5, 1e-6, "fwd256 resid")
+    if N % 64 == 0:  # dgrad contracts over N
+        dy = torch.randint(-3, 4, (M, N), generator=g).float()
+        _assert_close(K.linear_dgrad(_bf(dy).to(DEV), _bf(w).to(DEV)), (dy @ w).to(torch.bfloat16), 0, 0, "dgrad256")
+
+
+@pytest.mark.parametrize("T,N,K_", [(16384, 768, 2304), (32768, 776, 264)])
+def test_gemm256_wgrad_layout(K, T, N, K_):
+    g = torch.Generator().manual_seed(T + N)
+    dy = torch.randint(-2, 3, (T, N), generator=g).float()
+    x = torch.randint(-2, 3, (T, K_), generator=g).float()
+    got = K.linear_wgrad(_bf(dy).to(DEV), _bf(x).to(DEV))
+    _assert_close(got, dy.t() @ x, 0, 0, "wgrad256")
+
+
 def test_gemm_random_tolerance(K):
     """Random normal data: bf16 inputs, fp32 accumulation; error bound 2e-3 relative to sqrt(K)."""
     g = torch.Generator().manual_seed(3)
