@@ -232,7 +232,7 @@ int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {
     // dW = dy^T x: few output tiles, contraction over all tokens.  Aim at ~2 workgroups per CU.
     const int64_t t256 = tiles_of(M, N, 256);
     if (K % 64 == 0 && K >= 8192) {
-        int64_t s = (512 + t256 - 1) / t256;
+        int64_t s = 256 / t256;  // one 512-thread workgroup per CU, all resident in a single wave of the grid
         if (s > K / 2048) s = K / 2048;
         if (s < 1) s = 1;
         if (t256 * s >= 200) return (int)s;

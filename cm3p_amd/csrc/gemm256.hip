@@ -148,23 +148,60 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         __syncthreads();                                   // everyone's has, and everyone is done reading `cur`
     }
 
+    // ---- epilogue through LDS: fragment-shaped accumulators -> whole rows -> 16-byte coalesced stores ---------------
+    // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
+    //  store-issue bound.)  The k-loop's final barrier has passed, so the whole LDS allocation is free.
+    if constexpr (EPI == CM3P_EPI_BF16) {
+        constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
+        uint16_t* C = static_cast<uint16_t*>(Cv);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
-        if (m >= M) continue;
+        for (int pass = 0; pass < 2; ++pass) {  // 128 rows per pass = the rows of waves with wm == pass
+            if (wm == pass) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-            if (n >= N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (EPI == CM3P_EPI_BF16) {
-                uint16_t* C = static_cast<uint16_t*>(Cv);
-                *reinterpret_cast<uint2*>(C + m * ldc + n) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-            } else {
-                float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
-                if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
-                *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = acc[i][j];
+                        const int r = i * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                        *reinterpret_cast<uint2*>(smem + r * kRow + cidx * 2) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+                    }
             }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
+                const int64_t m = m0 + pass * 128 + r, n = n0 + ch * 8;
+                if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(smem + r * kRow + ch * 16);
+            }
+            __syncthreads();
+        }
+    } else {
+        constexpr int kRow = TN * 4 + 16;
+        float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {  // 64 rows per pass: waves with wm == pass/2, accumulator rows i in [4*(pass&1), +4)
+            if (wm == (pass >> 1)) {
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = acc[(pass & 1) * 4 + i4][j];  // pass loop is fully unrolled: static register index
+                        const int r = i4 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                        *reinterpret_cast<f32x4*>(smem + r * kRow + cidx * 4) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 4;
+                if (m < M && n < N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * kRow + ch * 16);
+                    if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
+                    *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+                }
+            }
+            __syncthreads();
         }
     }
 }
