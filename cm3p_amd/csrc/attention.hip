@@ -61,6 +61,17 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sp) {
     return r;
 }
 
+// fragment * c, rounded back to bf16: folds softmax's scale*log2(e) into one MFMA operand so that the accumulator is
+// already in exp2 units (saves one VALU op per score)
+__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((float)v[j] * c);
+    return r;
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 struct TileRegs64 {  // a 64-row x 64-col bf16 tile spread over 256 threads: 2 x 16 bytes each
     uint4 v[2];
 };
@@ -89,12 +100,10 @@ __device__ __forceinline__ void lstore64_T(char* tile, const TileRegs64& t, int 
     }
 }
 
-__device__ __forceinline__ float reg_max16(const f32x16& a) {
-    float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
-    float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
-    float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+__device__ __forceinline__ float reg_max16(const f32x16& a) {  // 8 x v_max3_f32
+    const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+    const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+    return max3(max3(m0, m1, m2), max3(m3, m4, a[15]), m0);
 }
 
 // Visibility of keys (tile key0 + 32*blk + accumulator rows) for this lane's query: invisible scores become -inf.
@@ -141,10 +150,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const int qrow = q0 + (lane & 31);
     const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
     const int qrow_c = qrow < S ? qrow : S - 1;
-    bf16x8 qf[4];
+    const float c = scale * kLog2e;
+    bf16x8 qf[4];  // Q * (scale * log2 e): scores come out of the MFMA in exp2 units
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+        qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh), c);
 
     const int Q1 = min(S, Q0 + 128) - 1;
     int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
@@ -160,8 +170,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
-    float m_run = kNegInf, l_run = 0.f;
-    const float c = scale * kLog2e;
+    // Softmax state per query (= per lane): mc_run is the reference point in log2 units that every stored p, l and O is
+    // relative to; it is subtracted inside the MFMA (as the initial accumulator) and only moved when a tile maximum
+    // exceeds it by more than 2^kDefer ("lazy max": exact in exact arithmetic, the reference point divides out).
+    float mc_run = 0.f, l_run = 0.f;
+    bool has_ref = false;  // no finite score seen yet
+    constexpr float kDefer = 6.0f;
 
     TileRegs64 kr, vr;
     uint8_t mreg = 0;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
+                for (int i = 0; i < 16; ++i) sacc[blk][i] = -mc_run;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
             }
@@ -209,27 +223,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
                 mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
                 mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
             }
-            float mt = fmaxf(reg_max16(sacc[0]), reg_max16(sacc[1]));
+            float mt = fmaxf(reg_max16(sacc[0]), reg_max16(sacc[1]));  // tile max relative to mc_run
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m_run, mt);
-            const float mc = (m_new == kNegInf) ? 0.f : m_new * c;
-            const float alpha = __builtin_amdgcn_exp2f(m_run * c - mc);  // m_run = -inf -> 0
-            m_run = m_new;
+            const bool move = has_ref ? (mt > kDefer) : (mt > kNegInf);
+            if (__any(move)) {  // rare after the first tiles: shift the reference point of the rows that need it
+                const float shift = has_ref ? fmaxf(mt, 0.f) : (mt > kNegInf ? mt : 0.f);
+                const float alpha = has_ref ? __builtin_amdgcn_exp2f(-shift) : 1.0f;  // O = l = 0 before the first score
+                has_ref = has_ref || (mt > kNegInf);
+                mc_run += shift;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sacc[0][i] -= shift;
+                    sacc[1][i] -= shift;
+                    oacc[0][i] *= alpha;
+                    oacc[1][i] *= alpha;
+                }
+            }
             float psum = 0.f;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i] * c - mc);
+                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i]);
                     sacc[blk][i] = p;
                     psum += p;
                 }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                oacc[0][i] *= alpha;
-                oacc[1][i] *= alpha;
-            }
+            l_run += psum;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 pf = acc_to_frag(sacc[s >> 1], s & 1);
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
                 *reinterpret_cast<uint2*>(orow + dv) = w;
             }
         if (hh == 0)
-            lse[((int64_t)b * nh + head) * S + qrow] = l_tot > 0.f ? m_run * scale + __logf(l_tot) : __builtin_huge_valf();
+            lse[((int64_t)b * nh + head) * S + qrow] = l_tot > 0.f ? (mc_run + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
     }
 }
 
@@ -295,7 +315,9 @@ constexpr int kDqStage = 3 * 8192 + 64 + 16;
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                             int S, int nh, int window, float scale) {
+                                                             int S, int nh, int window, float scale,
+                                                             const float* __restrict__ rope_cos,
+                                                             const float* __restrict__ rope_sin, int64_t pos_batch_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
@@ -311,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const int qrow = q0 + (lane & 31);
     const int qrow_c = qrow < S ? qrow : S - 1;
     const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
-    bf16x8 qf[4], dof[4];
+    const float c = scale * kLog2e;
+    bf16x8 qf[4], dof[4];  // qf = Q * (scale * log2 e): K qf^T - lse*log2(e) is log2 of the probability
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+        qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh), c);
         dof[s] = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
     }
-    const float c = scale * kLog2e;
     const int64_t stat = ((int64_t)b * nh + head) * S + qrow_c;
     const float lse2 = lse[stat] * kLog2e;  // +inf for rows with no visible key -> p = 0
     const float dlt = delta[stat];
@@ -374,7 +396,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[blk][i] = dp[blk][i] = 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    sacc[blk][i] = -lse2;  // row constants as initial accumulators: log2 p, and dP - delta
+                    dp[blk][i] = -dlt;
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
@@ -390,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i] * c - lse2);
-                    sacc[blk][i] = p * (dp[blk][i] - dlt) * scale;  // dS^T
+                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i]);
+                    sacc[blk][i] = p * dp[blk][i];  // dS^T / scale (the scale is applied once, to dQ)
                 }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -406,12 +431,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 
     if (qrow < S) {
         uint16_t* drow = dqkv + ((int64_t)b * S + qrow) * ld + head * 64;
+        if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
+            const int64_t prow = (int64_t)b * pos_batch_stride + qrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 lo4 = {dq[0][4 * g], dq[0][4 * g + 1], dq[0][4 * g + 2], dq[0][4 * g + 3]};
+                f32x4 hi4 = {dq[1][4 * g], dq[1][4 * g + 1], dq[1][4 * g + 2], dq[1][4 * g + 3]};
+                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dq[0][4 * g + r] = lo4[r];
+                    dq[1][4 * g + r] = hi4[r];
+                }
+            }
+        }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 32 * blk + 8 * g + 4 * hh;
-                const uint2 w = {pack_bf16x2(dq[blk][4 * g], dq[blk][4 * g + 1]), pack_bf16x2(dq[blk][4 * g + 2], dq[blk][4 * g + 3])};
+                const uint2 w = {pack_bf16x2(dq[blk][4 * g] * scale, dq[blk][4 * g + 1] * scale),
+                                 pack_bf16x2(dq[blk][4 * g + 2] * scale, dq[blk][4 * g + 3] * scale)};
                 *reinterpret_cast<uint2*>(drow + d) = w;
             }
     }
@@ -427,7 +467,9 @@ constexpr int kDkvStage = 4 * 8192 + 512;
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                              int S, int nh, int window, float scale) {
+                                                              int S, int nh, int window, float scale,
+                                                              const float* __restrict__ rope_cos,
+                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
@@ -444,17 +486,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
     const int krow = k0 + (lane & 31);
     const int krow_c = krow < S ? krow : S - 1;
-    bf16x8 kf[4], vf[4];
+    const float c = scale * kLog2e;
+    bf16x8 kf[4], vf[4];  // kf = K * (scale * log2 e)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+        kf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh), c);
         vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
     }
     const bool key_ok = krow < S && (kmask ? kmask[(int64_t)b * S + krow] != 0 : true);
     const bool keys_all_ok = __all(key_ok);
     const int lo = window < 0 ? INT_MIN : krow - window, hi = window < 0 ? INT_MAX : krow + window;
-    const float c = scale * kLog2e;
-    const float inv_scale = 1.0f / scale;
 
     const int K1 = min(S, K0 + 128) - 1;
     int qlo = 0, qhi = S - 1, wlo = 0, whi = S - 1;
@@ -478,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         gload64(gr, dobase, ldo, t * 64, S, tid);
         if (tid < 128) {
             const int q = t * 64 + (tid & 63);
-            if (tid < 64) sreg = q < S ? -lse_bh[q] * inv_scale : kNegInf;  // -lse/scale; rows past S contribute p = 0
+            if (tid < 64) sreg = q < S ? -lse_bh[q] * kLog2e : kNegInf;  // -lse in log2 units; rows past S contribute p = 0
             else sreg = q < S ? -dlt_bh[q] : 0.f;
         }
     };
@@ -507,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {  // two 32-query blocks of the tile
                 f32x16 sacc, dp;
-                // initial accumulators: row constants -lse/scale and -delta (rows = queries)
+                // initial accumulators: row constants -lse*log2(e) and -delta (rows = queries)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 32 * qb + 8 * g + 4 * hh);
@@ -520,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);           // S - lse/scale, rows q, col key
+                    sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);           // log2 p: rows q, col key
                     dp = mfma32(frag_R(st + 16384, 32 * qb, s, lane), vf[s], dp);       // dP - delta
                 }
                 // every (query, key) pair of this 32 x 32 block visible?  (queries past S carry -inf and give p = 0 anyway)
@@ -529,9 +570,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 if (plain) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[i] * c);
+                        const float p = __builtin_amdgcn_exp2f(sacc[i]);
                         sacc[i] = p;
-                        dp[i] = p * dp[i] * scale;  // dS
+                        dp[i] = p * dp[i];  // dS / scale (applied once, to dK)
                     }
                 } else {
 #pragma unroll
@@ -541,9 +582,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                             const int i = 4 * g + r;
                             const int q = qb0 + 8 * g + 4 * hh + r;
                             const bool ok = key_ok & (q >= lo) & (q <= hi);
-                            const float p = ok ? __builtin_amdgcn_exp2f(sacc[i] * c) : 0.f;
+                            const float p = ok ? __builtin_amdgcn_exp2f(sacc[i]) : 0.f;
                             sacc[i] = p;
-                            dp[i] = p * dp[i] * scale;  // dS
+                            dp[i] = p * dp[i];  // dS / scale (applied once, to dK)
                         }
                 }
 #pragma unroll
@@ -565,13 +606,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     if (krow < S) {
         uint16_t* dkrow = dqkv + ((int64_t)b * S + krow) * ld + nh * 64 + head * 64;
         uint16_t* dvrow = dkrow + nh * 64;
+        if (rope_cos) {
+            const int64_t prow = (int64_t)b * pos_batch_stride + krow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 lo4 = {dk[0][4 * g], dk[0][4 * g + 1], dk[0][4 * g + 2], dk[0][4 * g + 3]};
+                f32x4 hi4 = {dk[1][4 * g], dk[1][4 * g + 1], dk[1][4 * g + 2], dk[1][4 * g + 3]};
+                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dk[0][4 * g + r] = lo4[r];
+                    dk[1][4 * g + r] = hi4[r];
+                }
+            }
+        }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 32 * blk + 8 * g + 4 * hh;
                 *reinterpret_cast<uint2*>(dkrow + d) =
-                    uint2{pack_bf16x2(dk[blk][4 * g], dk[blk][4 * g + 1]), pack_bf16x2(dk[blk][4 * g + 2], dk[blk][4 * g + 3])};
+                    uint2{pack_bf16x2(dk[blk][4 * g] * scale, dk[blk][4 * g + 1] * scale),
+                          pack_bf16x2(dk[blk][4 * g + 2] * scale, dk[blk][4 * g + 3] * scale)};
                 *reinterpret_cast<uint2*>(dvrow + d) =
                     uint2{pack_bf16x2(dv[blk][4 * g], dv[blk][4 * g + 1]), pack_bf16x2(dv[blk][4 * g + 2], dv[blk][4 * g + 3])};
             }
@@ -594,7 +650,10 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
 }
 
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, void* stream) {
+                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
+                  const float* sin_tab, int64_t pos_batch_stride, void* stream) {
+    CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
+    CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -605,10 +664,10 @@ int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
     CM3P_LAUNCH_CHECK();
     const dim3 grid((S + 127) / 128, nh, B);
     attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                       key_mask, S, nh, window, scale);
+                                                       key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride);
     CM3P_LAUNCH_CHECK();
     attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                         key_mask, S, nh, window, scale);
+                                                         key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

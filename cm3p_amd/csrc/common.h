@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CM3P_WAVE 64
+#define CM3P_EPI_BF16_ROPE 3  // internal: bf16 output with rotary embedding applied to the leading columns
 
 // Every extern "C" entry point ends with this: kernels never throw, launch errors become a return code.
 #define CM3P_LAUNCH_CHECK()                                         \
@@ -38,6 +39,32 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// Rotary tables for epilogue fusion: cos/sin are [n_pos, 32] fp32; a token row m uses table row (per_batch ? m : m % S);
+// only the first `ncols` output columns (the q and k thirds of a packed qkv row) are rotated.
+struct RopeArgs {
+    const float* cos;
+    const float* sin;
+    int S;
+    int per_batch;
+    int ncols;
+};
+
+// a = head dims [d, d+3], b = head dims [d+32, d+35] of one token (d < 32): rotate_half convention
+// (TF:models/modernbert/modeling_modernbert.py:188-219).  INVERSE applies the transpose (backward pass).
+template <bool INVERSE>
+__device__ __forceinline__ void rope_rotate4(f32x4& a, f32x4& b, const float* cos_row, const float* sin_row, int d) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_row + d);
+    const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_row + d);
+    const f32x4 a0 = a, b0 = b;
+    if constexpr (!INVERSE) {
+        a = a0 * cs - b0 * sn;
+        b = b0 * cs + a0 * sn;
+    } else {
+        a = a0 * cs + b0 * sn;
+        b = b0 * cs - a0 * sn;
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

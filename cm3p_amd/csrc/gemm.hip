@@ -94,7 +94,7 @@ template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                            void* __restrict__ Cv, const float* R, int64_t M, int64_t N,
                                                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_n,
-                                                           int64_t kchunk, int64_t c_split_stride) {
+                                                           int64_t kchunk, int64_t c_split_stride, RopeArgs rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -166,12 +166,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
         if (m >= M) continue;
+        if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+            // the wave's 64 columns are one head: dims d and d+32 sit in accumulator tiles j and j+2 of the same lane
+            if (n0 + wn * 64 < rope.ncols) {
+                const int64_t prow = rope.per_batch ? m : m % rope.S;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= N) continue;
             f32x4 v = acc[i][j];
-            if constexpr (EPI == CM3P_EPI_BF16) {
+            if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
                 uint16_t* C = static_cast<uint16_t*>(Cv);
                 *reinterpret_cast<uint2*>(C + m * ldc + n) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             } else {
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <bool A_KC, bool B_KC>
 int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-           int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s) {
+           int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope = RopeArgs{}) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
     const dim3 grid(tiles_m * tiles_n, 1, splits);
     const size_t lds = 4 * kStageBytes;
@@ -203,14 +212,20 @@ int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int
     const uint16_t* b = static_cast<const uint16_t*>(B);
     switch (epi) {
         case CM3P_EPI_BF16:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_BF16><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_BF16><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
             break;
         case CM3P_EPI_F32:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
             break;
         case CM3P_EPI_F32_RESID:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32_RESID><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32_RESID><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
             break;
+        case CM3P_EPI_BF16_ROPE:
+            if constexpr (A_KC && B_KC) {
+                gemm_bf16_kernel<true, true, CM3P_EPI_BF16_ROPE><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
+                break;
+            }
+            return CM3P_ERR_INVALID;
         default:
             return CM3P_ERR_INVALID;
     }
@@ -222,7 +237,7 @@ int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int
 // gemm256.hip: the 256 x 256 LDS-DMA kernel for the big shapes
 int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                           int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
-                          int64_t c_split_stride, hipStream_t s);
+                          int64_t c_split_stride, hipStream_t s, RopeArgs rope);
 
 static inline int64_t tiles_of(int64_t M, int64_t N, int t) { return ((M + t - 1) / t) * ((N + t - 1) / t); }
 
@@ -244,9 +259,27 @@ int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {
     return (int)(s < 1 ? 1 : s);
 }
 
+int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, int64_t N, int64_t K, const float* cos_tab,
+                       const float* sin_tab, int S, int per_batch, int rope_cols, void* stream) {
+    CM3P_REQUIRE(x && Wqkv && qkv && cos_tab && sin_tab && M > 0 && N > 0 && K > 0 && S > 0);
+    CM3P_REQUIRE(cm3p_aligned16(x) && cm3p_aligned16(Wqkv) && cm3p_aligned16(qkv) && cm3p_aligned16(cos_tab) && cm3p_aligned16(sin_tab));
+    CM3P_REQUIRE(K % 8 == 0 && N % 64 == 0 && rope_cols % 64 == 0 && rope_cols >= 0 && rope_cols <= N);
+    CM3P_REQUIRE(per_batch || M % S == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RopeArgs rope{cos_tab, sin_tab, S, per_batch, rope_cols};
+    const bool big = (K % 64 == 0) && tiles_of(M, N, 256) >= 200;
+    int rc;
+    if (big) rc = cm3p_gemm256_dispatch(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, 1, 1, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
+    else rc = launch<true, true>(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
+    if (rc != CM3P_OK) return rc;
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream) {
     CM3P_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
+    CM3P_REQUIRE(epilogue >= CM3P_EPI_BF16 && epilogue <= CM3P_EPI_F32_RESID);
     CM3P_REQUIRE(cm3p_aligned16(A) && cm3p_aligned16(B) && cm3p_aligned16(C));
     CM3P_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && N % 4 == 0);
     CM3P_REQUIRE(a_kc ? (K % 8 == 0 && lda >= K) : (M % 8 == 0 && lda >= M));
@@ -268,7 +301,7 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
     }
     int rc;
     const bool big = (K % 64 == 0) && (kchunk % 64 == 0) && tiles_of(M, N, 256) * split_k >= 200;
-    if (big) rc = cm3p_gemm256_dispatch(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s);
+    if (big) rc = cm3p_gemm256_dispatch(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s, RopeArgs{});
     else if (a_kc && b_kc) rc = launch<true, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (a_kc) rc = launch<true, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (b_kc) rc = launch<false, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);

@@ -84,7 +84,7 @@ template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                          void* __restrict__ Cv, const float* R, int64_t M, int64_t N, int64_t K,
                                                          int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int64_t kchunk,
-                                                         int64_t c_split_stride) {
+                                                         int64_t c_split_stride, RopeArgs rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,7 +151,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     // ---- epilogue through LDS: fragment-shaped accumulators -> whole rows -> 16-byte coalesced stores ---------------
     // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
     //  store-issue bound.)  The k-loop's final barrier has passed, so the whole LDS allocation is free.
-    if constexpr (EPI == CM3P_EPI_BF16) {
+    if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+        // rotate in registers, in fp32, before rounding: the wave's 64 columns are one head, dims d and d+32 are
+        // accumulator tiles j and j+2 of the same lane
+        if (n0 + wn * 64 < rope.ncols) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+                if (m > M - 1) m = M - 1;
+                const int64_t prow = rope.per_batch ? m : m % rope.S;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
+            }
+        }
+    }
+    if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
         constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
         uint16_t* C = static_cast<uint16_t*>(Cv);
 #pragma unroll
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 
 template <bool A_KC, bool B_KC>
 int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
-              int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s) {
+              int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const dim3 grid(tiles_m * tiles_n, 1, splits);
     const size_t lds = 2 * kStage;
@@ -221,12 +236,18 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
                 return CM3P_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride); \
+        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G256(CM3P_EPI_BF16) break;
         case CM3P_EPI_F32: CM3P_G256(CM3P_EPI_F32) break;
         case CM3P_EPI_F32_RESID: CM3P_G256(CM3P_EPI_F32_RESID) break;
+        case CM3P_EPI_BF16_ROPE:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G256(CM3P_EPI_BF16_ROPE)
+                break;
+            }
+            return CM3P_ERR_INVALID;
         default: return CM3P_ERR_INVALID;
     }
 #undef CM3P_G256
@@ -238,11 +259,11 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
 // Internal entry used by cm3p_gemm_bf16 (gemm.hip) when the shape qualifies; not part of the public header.
 int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                           int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
-                          int64_t c_split_stride, hipStream_t s) {
+                          int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(B);
-    if (a_kc && b_kc) return launch256<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
-    if (a_kc) return launch256<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
-    if (b_kc) return launch256<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
-    return launch256<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s);
+    if (a_kc && b_kc) return launch256<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (a_kc) return launch256<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (b_kc) return launch256<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    return launch256<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
 }

@@ -113,8 +113,7 @@ class _EncoderStackFn(torch.autograd.Function):
                 xn, mean_a, rstd_a = K.cast_bf16(x), None, None
             else:
                 _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, geo.save)
-            qkv = K.linear_fwd(xn, Wqkv_b)
-            K.rope_apply_(qkv, cos, sin, B, S, nh, geo.per_batch_pos)
+            qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
             o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
             x_mid = K.linear_fwd(o, Wo_b, resid=x)
             _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, geo.save)
@@ -164,10 +163,9 @@ class _EncoderStackFn(torch.autograd.Function):
             # ---- attention branch: x_mid = x + o Wo^T
             do = K.linear_dgrad(gx16, Wo_b)
             dWo = K.linear_wgrad(gx16, o)
-            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale)
+            # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
+            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
             del do, o, qkv
-            cos, sin = geo.rope[i]
-            K.rope_apply_(dqkv, cos, sin, B, S, nh, geo.per_batch_pos, inverse=True)
             dxn = K.linear_dgrad(dqkv, Wqkv_b)
             dWqkv = K.linear_wgrad(dqkv, xn)
             del dqkv, xn

@@ -104,6 +104,16 @@ def linear_fwd(x: Tensor, w: Tensor, resid: Optional[Tensor] = None) -> Tensor:
     return gemm(x, w, T, N, K, True, True, EPI_F32_RESID if resid is not None else EPI_BF16, resid)
 
 
+def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_batch: bool) -> Tensor:
+    """Fused Wqkv projection + RoPE on the q and k thirds: x [T,H] bf16, w [3H,H] bf16 -> qkv [T,3H] bf16 (rotated)."""
+    T, Kd = x.shape
+    N = w.shape[0]
+    out = _empty((T, N), torch.bfloat16, x)
+    call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos), ptr(sin), S, int(per_batch), 2 * N // 3, stream(),
+         tag="gemm_bf16_kernel<1,1,rope>", work=2.0 * T * N * Kd)
+    return out
+
+
 def linear_dgrad(dy: Tensor, w: Tensor) -> Tensor:
     """dy [T,N] bf16, w [N,K] bf16 -> dx [T,K] bf16 = dy w."""
     T, N = dy.shape
@@ -156,12 +166,14 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
-             window: int, scale: float) -> Tensor:
+             window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False) -> Tensor:
+    """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM)."""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
+    cos, sin = rope if rope is not None else (None, None)
     call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(key_mask), B, S, nh, window, scale,
-         stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
+         ptr(cos), ptr(sin), S if per_batch else 0, stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
     return dqkv
 
 

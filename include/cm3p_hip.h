@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 1
+#define CM3P_ABI_VERSION 2
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -92,6 +92,13 @@ int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int3
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
 
+/* Fused Wqkv projection + rotary embedding: qkv[M, N] (bf16) = x[M, K] Wqkv[N, K]^T with apply_rotary_pos_emb applied to the
+ * first rope_cols (= 2H: the q and k thirds) columns in the fp32 accumulators before rounding
+ * (TF:...modeling_modernbert.py:271-280).  cos/sin: [n_pos, 32] fp32 from cm3p_rope_table; token row m uses table row
+ * m (per_batch != 0) or m % S.  Heads are 64 wide; N and rope_cols are multiples of 64. */
+int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, int64_t N, int64_t K, const float* cos_tab,
+                       const float* sin_tab, int S, int per_batch, int rope_cols, void* stream);
+
 /* Host-only: the split_k the library recommends for a weight-gradient GEMM of this shape (sizes the workspace). */
 int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K);
 
@@ -128,9 +135,12 @@ int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B
  */
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                   float scale, void* stream);
-/* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten. */
+/* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten.
+ * If cos_tab/sin_tab are not NULL the inverse rotary rotation is applied to dq and dk before they are stored (the
+ * backward of apply_rotary_pos_emb), with pos_batch_stride = 0 (one position row for all batches) or S. */
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, void* stream);
+                  const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
+                  const float* sin_tab, int64_t pos_batch_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GeGLU: g = gelu_erf(h[:, :I]) * h[:, I:]   (ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91).

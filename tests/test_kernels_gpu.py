@@ -217,6 +217,35 @@ def test_rope_matches_reference_formula(K, per_batch):
     _assert_close(buf[:, :, :2], qkv[:, :, :2], 2e-2, 2e-2, "rope inverse")
 
 
+@pytest.mark.parametrize("T,S,nh,per_batch", [(600, 300, 2, False), (600, 300, 2, True), (8192, 2048, 12, False)])
+def test_fused_qkv_rope_gemm_and_inverse_in_attention_backward(K, T, S, nh, per_batch):
+    """Wqkv GEMM with the rotary epilogue == plain GEMM followed by the stand-alone RoPE kernel (bf16 ulp: the fused path
+    rotates fp32 accumulators before rounding); attention backward with the fused inverse rotation == separate passes."""
+    from oracle import cm3p_oracle as O
+
+    g = torch.Generator().manual_seed(T + nh)
+    H, B = nh * 64, T // S
+    x = _bf(torch.randn(T, H, generator=g)).to(DEV)
+    w = _bf(torch.randn(3 * H, H, generator=g) * H ** -0.5).to(DEV)
+    pos = torch.arange(S).unsqueeze(0) if not per_batch else torch.stack([torch.arange(S) + 7 * b for b in range(B)])
+    cos, sin = K.rope_table(pos.to(DEV), O.rope_inv_freq(10000.0, 64).to(DEV))
+    ref = K.linear_fwd(x, w)
+    # the packed layout per token is [3][nh][64]; the GEMM output row is exactly that
+    K.rope_apply_(ref, cos, sin, B, S, nh, per_batch)
+    got = K.qkv_linear_rope(x, w, cos, sin, S, per_batch)
+    _assert_close(got, ref, 2e-2, 1.6e-2, "fused qkv rope")
+    assert torch.equal(got.view(T, 3, H)[:, 2], ref.view(T, 3, H)[:, 2])  # v third untouched and bit-identical
+
+    qkv = got
+    do = _bf(torch.randn(T, H, generator=g)).to(DEV)
+    out, lse = K.attn_fwd(qkv, None, B, S, nh, -1, 0.125)
+    d_sep = K.attn_bwd(qkv, out, do, lse, None, B, S, nh, -1, 0.125)
+    K.rope_apply_(d_sep, cos, sin, B, S, nh, per_batch, inverse=True)
+    d_fused = K.attn_bwd(qkv, out, do, lse, None, B, S, nh, -1, 0.125, (cos, sin), per_batch)
+    scale_ = d_sep.float().abs().max().item()
+    _assert_close(d_fused, d_sep, 1e-2 * scale_, 1.6e-2, "fused inverse rope")
+
+
 def test_geglu_and_gelu(K):
     g = torch.Generator().manual_seed(9)
     T, I = 333, 192
@@ -277,7 +306,7 @@ def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True):
 
     km = mask.to(torch.uint8).to(DEV) if mask is not None else None
     out, lse = K.attn_fwd(qkv.to(DEV), km, B, S, nh, window, 0.125)
-    _assert_close(out, o.detach().to(torch.bfloat16), 2e-3, 2e-2, f"attn fwd S={S} w={window}")
+    _assert_close(out, o.detach().to(torch.bfloat16), 4e-3, 2e-2, f"attn fwd S={S} w={window}")  # q is pre-scaled in bf16
     # rows with no visible key are exact zeros
     if allowed is not None:
         dead = ~allowed.any(dim=-1).expand(B, nh, S).transpose(1, 2).reshape(B * S, nh)  # (B*S, nh)
@@ -314,6 +343,34 @@ def test_attention_sliding_window_padded_dead_rows(K):
 def test_attention_short_sequence(K):
     _attn_case(K, 2, 48, 1, 64, None, 5)
     _attn_case(K, 1, 1, 1, -1, None, 6)
+
+
+def test_attention_late_max_spike_forces_rescale(K):
+    """The forward keeps a lazily updated running max (rescale only when a tile max exceeds it by > 2^6).  Force the
+    rescale branch late in the key sweep: a key far into the sequence aligned with a few queries makes their max jump by
+    orders of magnitude at that tile; and scale half of the queries down so their rows never leave the lazy regime."""
+    from oracle import cm3p_oracle as O
+
+    g = torch.Generator().manual_seed(77)
+    B, S, nh = 1, 1024, 2
+    qkv = torch.randn(B, S, 3, nh, 64, generator=g)
+    qkv[:, ::2, 0] *= 0.05                       # flat rows: tile maxima stay within the deferral threshold
+    for qi, ki in ((100, 700), (101, 960), (900, 3)):
+        qkv[0, ki, 1] = 3.0 * qkv[0, qi, 0]      # score ~ 3 * |q|^2 / 8 >> every other score of that row
+    qkv = _bf(qkv)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    o = O.sdpa(q, k, v, None, 0.125, eager=True).transpose(1, 2).reshape(B * S, nh * 64)
+    do = _bf(torch.randn(B * S, nh * 64, generator=g))
+    o.backward(do.float())
+    out, lse = K.attn_fwd(qkv.to(DEV), None, B, S, nh, -1, 0.125)
+    _assert_close(out, o.detach().to(torch.bfloat16), 4e-3, 2e-2, "attn fwd spike")
+    s_ref = (q @ k.transpose(-1, -2) * 0.125).detach()
+    _assert_close(lse, torch.logsumexp(s_ref, dim=-1), 5e-3, 2e-3, "lse spike")
+    dqkv = K.attn_bwd(qkv.to(DEV), out, do.to(DEV), lse, None, B, S, nh, -1, 0.125)
+    for i, nm in enumerate("qkv"):
+        e = (dqkv[:, :, i].float().cpu() - x.grad[:, :, i]).norm() / x.grad[:, :, i].norm()
+        assert e < 2e-2, f"d{nm} relative L2 error {e:.3e}"
 
 
 def test_attention_long_sequence_properties(K):
