@@ -17,7 +17,7 @@ EPI_BF16, EPI_F32, EPI_F32_RESID = 0, 1, 2
 ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcm3p_hip.so")
+LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 

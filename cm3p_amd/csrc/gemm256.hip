@@ -80,144 +80,186 @@ __device__ __forceinline__ bf16x8 frag(const char* image, int idx0, int kk, int 
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for every global
+// store already issued - in the epilogue that serialises the passes on HBM write latency.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                          void* __restrict__ Cv, const float* R, int64_t M, int64_t N, int64_t K,
-                                                         int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int64_t kchunk,
-                                                         int64_t c_split_stride, RopeArgs rope) {
+                                                         int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int ntiles, int total,
+                                                         int64_t kchunk, int64_t c_split_stride, RopeArgs rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    const int tm = swz / tiles_n, tn = swz % tiles_n;
-    const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+    // Persistent workgroups: work item v = (k-split, tile); block b takes v = b, b + grid, ...  The XCD-aware (bijective)
+    // order gives the blocks of one XCD (b % 8 equal) neighbouring tiles in every round, so operand panels are re-read
+    // from that XCD's L2.  Speed only: any order is correct.
+    const int q8 = total / 8, r8 = total % 8;
+    auto decode = [&](int v, int64_t& m0, int64_t& n0, int& z) {
+        const int xcd = v % 8;
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + v / 8;
+        z = swz / ntiles;
+        const int t = swz - z * ntiles;
+        m0 = (int64_t)(t / tiles_n) * TM;
+        n0 = (int64_t)(t % tiles_n) * TN;
+    };
 
-    const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
-    const int64_t kend = min(K, kbeg + kchunk);
-    const int nk = (int)((kend - kbeg) / TK);  // K % 64 == 0 on this path
+    int v = blockIdx.x;
+    int64_t m0, n0;
+    int z;
+    decode(v, m0, n0, z);
+    int64_t kbeg = (int64_t)z * kchunk;
+    int nk = (int)((min(K, kbeg + kchunk) - kbeg) / TK);  // K % 64 == 0 on this path
 
     Stager<A_KC> sa;
     Stager<B_KC> sb;
     sa.init(A, lda, m0, M, kbeg, wid, lane);
     sb.init(B, ldb, n0, N, kbeg, wid, lane);
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (nk > 0) {
-        sa.issue(smem, wid);
-        sb.issue(smem + kOperandBytes, wid);
-    }
+    int stage = 0;
+    sa.issue(smem, wid);
+    sb.issue(smem + kOperandBytes, wid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * kStage;
-        char* nxt = smem + ((kt + 1) & 1) * kStage;
-        if (kt + 1 < nk) {
-            sa.issue(nxt, wid);
-            sb.issue(nxt + kOperandBytes, wid);
-        }
-        const char* ia = cur;
-        const char* ib = cur + kOperandBytes;
+    while (true) {
+        f32x4 acc[8][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fb[4];
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                bf16x8 fa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for the next stage has landed
-        __syncthreads();                                   // everyone's has, and everyone is done reading `cur`
-    }
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- epilogue through LDS: fragment-shaped accumulators -> whole rows -> 16-byte coalesced stores ---------------
-    // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
-    //  store-issue bound.)  The k-loop's final barrier has passed, so the whole LDS allocation is free.
-    if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
-        // rotate in registers, in fp32, before rounding: the wave's 64 columns are one head, dims d and d+32 are
-        // accumulator tiles j and j+2 of the same lane
-        if (n0 + wn * 64 < rope.ncols) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
-                if (m > M - 1) m = M - 1;
-                const int64_t prow = rope.per_batch ? m : m % rope.S;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < total;
+        int64_t m0n = 0, n0n = 0, kbegn = 0;
+        int zn = 0, nkn = 0;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + stage * kStage;
+            char* nxt = smem + (stage ^ 1) * kStage;
+            if (kt + 1 < nk) {
+                sa.issue(nxt, wid);
+                sb.issue(nxt + kOperandBytes, wid);
+            } else if (has_next) {
+                // cross-tile prefetch: the first k-tile of the NEXT work item streams in under this item's last MFMAs and
+                // epilogue, so the next item starts without a load bubble
+                decode(vn, m0n, n0n, zn);
+                kbegn = (int64_t)zn * kchunk;
+                nkn = (int)((min(K, kbegn + kchunk) - kbegn) / TK);
+                sa.init(A, lda, m0n, M, kbegn, wid, lane);
+                sb.init(B, ldb, n0n, N, kbegn, wid, lane);
+                sa.issue(nxt, wid);
+                sb.issue(nxt + kOperandBytes, wid);
             }
-        }
-    }
-    if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
-        constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
-        uint16_t* C = static_cast<uint16_t*>(Cv);
+            const char* ia = cur;
+            const char* ib = cur + kOperandBytes;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {  // 128 rows per pass = the rows of waves with wm == pass
-            if (wm == pass) {
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fb[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = acc[i][j];
-                        const int r = i * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
-                        *reinterpret_cast<uint2*>(smem + r * kRow + cidx * 2) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
-                    }
-            }
-            __syncthreads();
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 fa[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
-                const int64_t m = m0 + pass * 128 + r, n = n0 + ch * 8;
-                if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(smem + r * kRow + ch * 16);
-            }
-            __syncthreads();
-        }
-    } else {
-        constexpr int kRow = TN * 4 + 16;
-        float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
+                    for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {  // 64 rows per pass: waves with wm == pass/2, accumulator rows i in [4*(pass&1), +4)
-            if (wm == (pass >> 1)) {
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = acc[(pass & 1) * 4 + i4][j];  // pass loop is fully unrolled: static register index
-                        const int r = i4 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
-                        *reinterpret_cast<f32x4*>(smem + r * kRow + cidx * 4) = v;
-                    }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
-                const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 4;
-                if (m < M && n < N) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * kRow + ch * 16);
-                    if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
-                    *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+                        for (int j = 0; j < 4; ++j)
+                            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for the other stage has landed
+            __syncthreads();                                   // everyone's has, and everyone is done reading `cur`
+            stage ^= 1;
         }
+
+        // ---- epilogue through LDS: fragment-shaped accumulators -> whole rows -> 16-byte coalesced stores -----------
+        // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
+        //  store-issue bound.)  `stage` now holds the next item's first k-tile (if any); the other 64 KiB are free.
+        char* ebuf = smem + (stage ^ 1) * kStage;
+        if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+            // rotate in registers, in fp32, before rounding: the wave's 64 columns are one head, dims d and d+32 are
+            // accumulator tiles j and j+2 of the same lane
+            if (n0 + wn * 64 < rope.ncols) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
+                    if (m > M - 1) m = M - 1;
+                    const int64_t prow = rope.per_batch ? m : m % rope.S;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
+                    __builtin_amdgcn_sched_barrier(0);  // keep the table loads of one row group at a time in flight (registers)
+                }
+            }
+        }
+        if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
+            constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
+            uint16_t* C = static_cast<uint16_t*>(Cv);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {  // 64 rows per pass: waves with wm == pass/2, accumulator rows i in [4*(pass&1), +4)
+                if (wm == (pass >> 1)) {
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a = acc[(pass & 1) * 4 + i4][j];
+                            const int r = i4 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            *reinterpret_cast<uint2*>(ebuf + r * kRow + cidx * 2) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
+                        }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
+                    const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 8;
+                    if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(ebuf + r * kRow + ch * 16);
+                }
+                lds_barrier();
+            }
+        } else {
+            constexpr int kRow = TN * 4 + 16;
+            float* C = static_cast<float*>(Cv) + (int64_t)z * c_split_stride;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {  // 32 rows per pass: waves with wm == pass/4, accumulator rows 2*(pass&3), +1
+                if (wm == (pass >> 2)) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a = acc[(pass & 3) * 2 + i2][j];  // pass loop fully unrolled: static register index
+                            const int r = i2 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            *reinterpret_cast<f32x4*>(ebuf + r * kRow + cidx * 4) = a;
+                        }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                    const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
+                    if (m < M && n < N) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(ebuf + r * kRow + ch * 16);
+                        if constexpr (EPI == CM3P_EPI_F32_RESID) a += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
+                        *reinterpret_cast<f32x4*>(C + m * ldc + n) = a;
+                    }
+                }
+                lds_barrier();
+            }
+        }
+
+        if (!has_next) break;
+        v = vn;
+        m0 = m0n;
+        n0 = n0n;
+        z = zn;
+        nk = nkn;
     }
 }
 
@@ -225,7 +267,15 @@ template <bool A_KC, bool B_KC>
 int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
               int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
-    const dim3 grid(tiles_m * tiles_n, 1, splits);
+    const int ntiles = tiles_m * tiles_n, total = ntiles * splits;
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    const dim3 grid(total < num_cu ? total : num_cu);  // one persistent 512-thread workgroup per CU
     const size_t lds = 2 * kStage;
 #define CM3P_G256(E)                                                                                                     \
     {                                                                                                                    \
@@ -236,7 +286,7 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
                 return CM3P_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope); \
+        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G256(CM3P_EPI_BF16) break;
