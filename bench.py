@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch (rehearsals only; the judged run uses the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing in the timed region")
     args = ap.parse_args()
@@ -132,15 +133,24 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and cm3p_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; CM3P_BENCH_BACKEND=gloo lets several ranks share one card for rehearsing the N>1 code path
+    backend = os.environ.get("CM3P_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from cm3p_amd import CM3PConfig, CM3PModel, _lib
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.batch:
+        w["B"] = args.batch
+        w["desc"] += f" [batch overridden to {args.batch}/GPU]"
     config = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))  # ref:configs/model/default.yaml
     torch.manual_seed(0)
     model = CM3PModel(config).to(device).train()  # random init of the named architecture, fp32 master weights
@@ -150,7 +160,7 @@ def main():
     step_model = model
     if world > 1:
         model.gather_negatives = True
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                                bucket_cap_mb=128)
     batch = make_batch(config, w, rank, device)
 

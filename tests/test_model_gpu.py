@@ -187,3 +187,57 @@ def test_gather_negatives_world_size_one_equals_local_loss():
         assert abs(model.logit_scale.grad.item() - s0.item()) <= 1e-4
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, name, out):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU of the test box
+    try:
+        torch.cuda.set_device(0)
+        blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+        model = _build(name)
+        model.gather_negatives = True
+        for p in model.beatmap_model.audio_encoder.parameters():
+            p.requires_grad_(False)  # no input_features in this case: DDP needs every trainable parameter to get a gradient
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        full = _inputs(blob)
+        b = full["input_ids"].shape[0] // world
+        part = {k: v[rank * b:(rank + 1) * b].contiguous() for k, v in full.items()}
+        o = ddp(**part)
+        o.loss.backward()
+        torch.cuda.synchronize()
+        out[rank] = (o.loss.item(), model.beatmap_model.encoder.layers[1].attn.Wqkv.weight.grad.cpu(),
+                     model.logit_scale.grad.cpu(), model.metadata_projection.weight.grad.cpu(), tuple(o.logits_per_metadata.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gathered_step_equals_single_process_global_batch():
+    """SURVEY §8e on the real kernels: 2 ranks (gloo, sharing cuda:0), DDP gradient averaging + all-gathered negatives
+    == one process on the concatenated batch.  Tolerance: bf16 re-rounding between the two decompositions (1e-2)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    name = "d64_cls_nopad"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(2, port, name, out), nprocs=2, join=True)
+
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name)
+    o = model(**_inputs(blob))
+    o.loss.backward()
+    losses = [out[r][0] for r in range(2)]
+    assert abs(sum(losses) / 2 - o.loss.item()) <= 2e-3
+    for r in range(2):
+        assert out[r][4] == (2, 4)  # this rank's 2 metadata rows against all 4 beatmaps
+        assert _rel(out[r][1], model.beatmap_model.encoder.layers[1].attn.Wqkv.weight.grad) <= 2e-2
+        assert abs(out[r][2].item() - model.logit_scale.grad.item()) <= 2e-3 * max(1.0, abs(model.logit_scale.grad.item()))
+        assert _rel(out[r][3], model.metadata_projection.weight.grad) <= 2e-2
