@@ -135,47 +135,60 @@ __device__ __forceinline__ bool tile_unmasked(int all_valid, int key0, int q0, i
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask bytes, all-valid flag
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                          float* __restrict__ lse, const uint8_t* __restrict__ kmask, int S,
-                                                          int nh, int window, float scale) {
+// QSUB = number of 32-query sub-blocks per wave.  With QSUB = 2 a wave carries two independent softmax chains: the
+// MFMAs of one sub-block overlap the VALU work of the other inside a single instruction stream (one wave cannot hide
+// its own MFMA -> VALU -> MFMA dependency), and every K / V fragment read from LDS feeds twice the work.
+template <int QSUB>
+__global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                                        float* __restrict__ lse, const uint8_t* __restrict__ kmask,
+                                                                        int S, int nh, int window, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QW = 32 * QSUB;  // queries per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int Q0 = blockIdx.x * 128;
-    const int q0 = Q0 + wid * 32;
+    const int Q0 = blockIdx.x * (4 * QW);
+    const int q0 = Q0 + wid * QW;
     const int64_t ld = (int64_t)3 * nh * 64;
     const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
-    const int qrow = q0 + (lane & 31);
-    const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
-    const int qrow_c = qrow < S ? qrow : S - 1;
     const float c = scale * kLog2e;
-    bf16x8 qf[4];  // Q * (scale * log2 e): scores come out of the MFMA in exp2 units
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh), c);
+    constexpr float kDefer = 6.0f;
 
-    const int Q1 = min(S, Q0 + 128) - 1;
+    int qrow[QSUB], lo[QSUB], hi[QSUB];
+    bf16x8 qf[QSUB][4];  // Q * (scale * log2 e): scores come out of the MFMA in exp2 units
+    f32x16 oacc[QSUB][2];
+    // Softmax state per query (= per lane): mc_run is the reference point in log2 units that every stored p, l and O is
+    // relative to; it is subtracted inside the MFMA (as the initial accumulator) and only moved when a tile maximum
+    // exceeds it by more than 2^kDefer ("lazy max": exact in exact arithmetic, the reference point divides out).
+    float mc_run[QSUB], l_run[QSUB];
+    bool has_ref[QSUB];
+#pragma unroll
+    for (int u = 0; u < QSUB; ++u) {
+        qrow[u] = q0 + 32 * u + (lane & 31);
+        lo[u] = window < 0 ? INT_MIN : qrow[u] - window;
+        hi[u] = window < 0 ? INT_MAX : qrow[u] + window;
+        const int qc = qrow[u] < S ? qrow[u] : S - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[u][s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 16 * s + 8 * hh), c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[u][0][i] = oacc[u][1][i] = 0.f;
+        mc_run[u] = 0.f;
+        l_run[u] = 0.f;
+        has_ref[u] = false;
+    }
+
+    const int Q1 = min(S, Q0 + 4 * QW) - 1;
     int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
     if (window >= 0) {
         klo = max(0, Q0 - window);
         khi = min(S - 1, Q1 + window);
         wlo = max(0, q0 - window);
-        whi = min(S - 1, q0 + 31 + window);
+        whi = min(S - 1, q0 + QW - 1 + window);
     }
     const bool wave_live = q0 < S;
     const int t_lo = klo / 64, t_hi = khi / 64;
-
-    f32x16 oacc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
-    // Softmax state per query (= per lane): mc_run is the reference point in log2 units that every stored p, l and O is
-    // relative to; it is subtracted inside the MFMA (as the initial accumulator) and only moved when a tile maximum
-    // exceeds it by more than 2^kDefer ("lazy max": exact in exact arithmetic, the reference point divides out).
-    float mc_run = 0.f, l_run = 0.f;
-    bool has_ref = false;  // no finite score seen yet
-    constexpr float kDefer = 6.0f;
 
     TileRegs64 kr, vr;
     uint8_t mreg = 0;
@@ -210,72 +223,94 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 
         const int key0 = t * 64;
         if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
-            f32x16 sacc[2];
+            f32x16 sacc[QSUB][2];
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int u = 0; u < QSUB; ++u)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[blk][i] = -mc_run;
+                for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
-            }
-            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 16448), key0, q0, window)) {
-                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
-                mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
-                mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
-            }
-            float mt = fmaxf(reg_max16(sacc[0]), reg_max16(sacc[1]));  // tile max relative to mc_run
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const bool move = has_ref ? (mt > kDefer) : (mt > kNegInf);
-            if (__any(move)) {  // rare after the first tiles: shift the reference point of the rows that need it
-                const float shift = has_ref ? fmaxf(mt, 0.f) : (mt > kNegInf ? mt : 0.f);
-                const float alpha = has_ref ? __builtin_amdgcn_exp2f(-shift) : 1.0f;  // O = l = 0 before the first score
-                has_ref = has_ref || (mt > kNegInf);
-                mc_run += shift;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    sacc[0][i] -= shift;
-                    sacc[1][i] -= shift;
-                    oacc[0][i] *= alpha;
-                    oacc[1][i] *= alpha;
-                }
-            }
-            float psum = 0.f;
+                    for (int i = 0; i < 16; ++i) sacc[u][blk][i] = -mc_run[u];
+            // S^T = K (cQ)^T - reference: each K fragment is read from LDS once and used by every sub-block
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i]);
-                    sacc[blk][i] = p;
-                    psum += p;
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 kf = frag_R(st, 32 * blk, s, lane);
+#pragma unroll
+                    for (int u = 0; u < QSUB; ++u) sacc[u][blk] = mfma32(kf, qf[u][s], sacc[u][blk]);
                 }
-            l_run += psum;
+            const int all_valid = *reinterpret_cast<const int*>(st + 16448);
+#pragma unroll
+            for (int u = 0; u < QSUB; ++u) {
+                if (!tile_unmasked(all_valid, key0, q0 + 32 * u, window)) {
+                    const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
+                    mask_scores_keyrows(sacc[u][0], mb, 0, key0, lo[u], hi[u], hh);
+                    mask_scores_keyrows(sacc[u][1], mb, 1, key0, lo[u], hi[u], hh);
+                }
+                float mt = fmaxf(reg_max16(sacc[u][0]), reg_max16(sacc[u][1]));  // tile max relative to mc_run
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                const bool move = has_ref[u] ? (mt > kDefer) : (mt > kNegInf);
+                if (__any(move)) {  // rare after the first tiles: shift the reference point of the rows that need it
+                    const float shift = has_ref[u] ? fmaxf(mt, 0.f) : (mt > kNegInf ? mt : 0.f);
+                    const float alpha = has_ref[u] ? __builtin_amdgcn_exp2f(-shift) : 1.0f;  // O = l = 0 before the first score
+                    has_ref[u] = has_ref[u] || (mt > kNegInf);
+                    mc_run[u] += shift;
+                    l_run[u] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        sacc[u][0][i] -= shift;
+                        sacc[u][1][i] -= shift;
+                        oacc[u][0][i] *= alpha;
+                        oacc[u][1][i] *= alpha;
+                    }
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[u][blk][i]);
+                        sacc[u][blk][i] = p;
+                        psum += p;
+                    }
+                l_run[u] += psum;
+            }
+            // O^T += V^T P^T: each V^T fragment (two transposed LDS reads) feeds every sub-block
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 pf = acc_to_frag(sacc[s >> 1], s & 1);
-                oacc[0] = mfma32(frag_T(st + 8192, 16 * s, 0, lane), pf, oacc[0]);
-                oacc[1] = mfma32(frag_T(st + 8192, 16 * s, 1, lane), pf, oacc[1]);
+                const bf16x8 v0 = frag_T(st + 8192, 16 * s, 0, lane);
+                const bf16x8 v1 = frag_T(st + 8192, 16 * s, 1, lane);
+#pragma unroll
+                for (int u = 0; u < QSUB; ++u) {
+                    const bf16x8 pf = acc_to_frag(sacc[u][s >> 1], s & 1);
+                    oacc[u][0] = mfma32(v0, pf, oacc[u][0]);
+                    oacc[u][1] = mfma32(v1, pf, oacc[u][1]);
+                }
             }
         }
         if (more) lstore(stage ^ 1);
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < S) {
-        uint16_t* orow = out + ((int64_t)b * S + qrow) * nh * 64 + head * 64;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+    for (int u = 0; u < QSUB; ++u) {
+        const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (qrow[u] < S) {
+            uint16_t* orow = out + ((int64_t)b * S + qrow[u]) * nh * 64 + head * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dv = 32 * blk + 8 * g + 4 * hh;
-                const uint2 w = {pack_bf16x2(oacc[blk][4 * g] * inv, oacc[blk][4 * g + 1] * inv),
-                                 pack_bf16x2(oacc[blk][4 * g + 2] * inv, oacc[blk][4 * g + 3] * inv)};
-                *reinterpret_cast<uint2*>(orow + dv) = w;
-            }
-        if (hh == 0)
-            lse[((int64_t)b * nh + head) * S + qrow] = l_tot > 0.f ? (mc_run + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = 32 * blk + 8 * g + 4 * hh;
+                    const uint2 w = {pack_bf16x2(oacc[u][blk][4 * g] * inv, oacc[u][blk][4 * g + 1] * inv),
+                                     pack_bf16x2(oacc[u][blk][4 * g + 2] * inv, oacc[u][blk][4 * g + 3] * inv)};
+                    *reinterpret_cast<uint2*>(orow + dv) = w;
+                }
+            if (hh == 0)
+                lse[((int64_t)b * nh + head) * S + qrow[u]] =
+                    l_tot > 0.f ? (mc_run[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
+        }
     }
 }
 
@@ -642,9 +677,15 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
                   float scale, void* stream) {
     CM3P_REQUIRE(qkv && out && lse && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
-    const dim3 grid((S + 127) / 128, nh, B);
-    attn_fwd_kernel<<<grid, 256, 2 * kFwdStage, static_cast<hipStream_t>(stream)>>>((const uint16_t*)qkv, (uint16_t*)out, lse,
-                                                                                   key_mask, S, nh, window, scale);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (window < 0 && S >= 512) {
+        // global layers: 64 queries per wave (two interleaved softmax chains), 256 queries per workgroup
+        const dim3 grid((S + 255) / 256, nh, B);
+        attn_fwd_kernel<2><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale);
+    } else {
+        const dim3 grid((S + 127) / 128, nh, B);
+        attn_fwd_kernel<1><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale);
+    }
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -11,15 +11,18 @@ namespace {
 
 constexpr int kMaxChunks = 8;  // 8 * 64 lanes * 4 floats = H <= 2048
 
+// A row of H values held by one wave: NC = ceil(H / 256) chunks of 64 lanes x 4 floats.  NC is a template parameter so
+// that H = 768 costs 3 chunks of registers and instructions, not the worst-case 8 (occupancy is what hides HBM latency).
+template <int NC>
 struct RowRegs {
-    f32x4 v[kMaxChunks];
+    f32x4 v[NC];
 };
 
 // load a row of H values (fp32 or bf16 source) into registers, lane owns columns c*256 + lane*4 .. +3
-template <bool SRC_BF16>
-__device__ __forceinline__ void load_row(RowRegs& r, const void* src, int H, int lane) {
+template <bool SRC_BF16, int NC>
+__device__ __forceinline__ void load_row(RowRegs<NC>& r, const void* src, int H, int lane) {
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) {
             if constexpr (SRC_BF16) {
@@ -34,14 +37,15 @@ __device__ __forceinline__ void load_row(RowRegs& r, const void* src, int H, int
     }
 }
 
-__device__ __forceinline__ void row_stats(const RowRegs& r, int H, int lane, float eps, float& mean, float& rstd) {
+template <int NC>
+__device__ __forceinline__ void row_stats(const RowRegs<NC>& r, int H, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) s += (r.v[c].x + r.v[c].y) + (r.v[c].z + r.v[c].w);
+    for (int c = 0; c < NC; ++c) s += (r.v[c].x + r.v[c].y) + (r.v[c].z + r.v[c].w);
     mean = wave_sum(s) / (float)H;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) {
             const f32x4 d = r.v[c] - mean;
@@ -52,10 +56,11 @@ __device__ __forceinline__ void row_stats(const RowRegs& r, int H, int lane, flo
     rstd = 1.0f / sqrtf(var + eps);
 }
 
-__device__ __forceinline__ void store_norm(const RowRegs& r, const float* __restrict__ w, float mean, float rstd,
+template <int NC>
+__device__ __forceinline__ void store_norm(const RowRegs<NC>& r, const float* __restrict__ w, float mean, float rstd,
                                            float* y32, uint16_t* y16, int H, int lane) {
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(w + col);
@@ -66,7 +71,7 @@ __device__ __forceinline__ void store_norm(const RowRegs& r, const float* __rest
     }
 }
 
-template <bool X_BF16>
+template <bool X_BF16, int NC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ y32, uint16_t* __restrict__ y16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -75,10 +80,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t row = wave; row < rows; row += nwaves) {
-        RowRegs r;
+        RowRegs<NC> r;
         const void* src = X_BF16 ? (const void*)(static_cast<const uint16_t*>(x) + row * H)
                                  : (const void*)(static_cast<const float*>(x) + row * H);
-        load_row<X_BF16>(r, src, H, lane);
+        load_row<X_BF16, NC>(r, src, H, lane);
         float mean, rstd;
         row_stats(r, H, lane, eps, mean, rstd);
         store_norm(r, w, mean, rstd, y32 ? y32 + row * H : nullptr, y16 ? y16 + row * H : nullptr, H, lane);
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
 // Backward.  xhat = (x - mean) * rstd, g = dy * w:
 //   dx = rstd * (g - mean_H(g) - xhat * mean_H(g * xhat)) [+ dres]      dw[col] = sum_rows dy * xhat
 // Each wave walks rows grid-stride and keeps its dw partial in registers; one partial row per block.
-template <bool DY_BF16>
+template <bool DY_BF16, int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in, const float* dres,
@@ -103,20 +108,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     const int wid = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    RowRegs dw;
+    RowRegs<NC> dw;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int64_t row = wave; row < rows; row += nwaves) {
-        RowRegs xr, gr;
-        load_row<false>(xr, x + row * H, H, lane);
+        RowRegs<NC> xr, gr;
+        load_row<false, NC>(xr, x + row * H, H, lane);
         const void* dsrc = DY_BF16 ? (const void*)(static_cast<const uint16_t*>(dy) + row * H)
                                    : (const void*)(static_cast<const float*>(dy) + row * H);
-        load_row<DY_BF16>(gr, dsrc, H, lane);
+        load_row<DY_BF16, NC>(gr, dsrc, H, lane);
         const float mean = mean_in[row], rstd = rstd_in[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H) {
                 const f32x4 xhat = (xr.v[c] - mean) * rstd;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H) {
                 f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
     // block-level reduction of the four waves' dw partials, fixed order -> deterministic
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) *reinterpret_cast<f32x4*>(dw_lds + wid * H + col) = dw.v[c];
     }
@@ -185,23 +190,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 // ---- embedding gather + LayerNorm ---------------------------------------------------------------------------
 // Source row of token t: override_rows[slot[t]] when slot && slot[t] >= 0 (audio placeholder,
 // ref:cm3p/modeling_cm3p.py:603-605), else table[ids[t]].
-template <bool TAB_BF16, bool OVR_BF16>
-__device__ __forceinline__ void load_embed_row(RowRegs& r, const int64_t* ids, const void* table, const int32_t* slot,
+template <bool TAB_BF16, bool OVR_BF16, int NC>
+__device__ __forceinline__ void load_embed_row(RowRegs<NC>& r, const int64_t* ids, const void* table, const int32_t* slot,
                                                const void* ovr, int64_t t, int H, int lane) {
     const int s = slot ? slot[t] : -1;
     if (s >= 0) {
         const void* src = OVR_BF16 ? (const void*)(static_cast<const uint16_t*>(ovr) + (int64_t)s * H)
                                    : (const void*)(static_cast<const float*>(ovr) + (int64_t)s * H);
-        load_row<OVR_BF16>(r, src, H, lane);
+        load_row<OVR_BF16, NC>(r, src, H, lane);
     } else {
         const int64_t id = ids[t];
         const void* src = TAB_BF16 ? (const void*)(static_cast<const uint16_t*>(table) + id * H)
                                    : (const void*)(static_cast<const float*>(table) + id * H);
-        load_row<TAB_BF16>(r, src, H, lane);
+        load_row<TAB_BF16, NC>(r, src, H, lane);
     }
 }
 
-template <bool TAB_BF16, bool OVR_BF16>
+template <bool TAB_BF16, bool OVR_BF16, int NC>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const void* __restrict__ table,
                                                            const int32_t* __restrict__ slot, const void* __restrict__ ovr,
                                                            const float* __restrict__ w, float* __restrict__ y32,
@@ -211,8 +216,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t t = wave; t < T; t += nwaves) {
-        RowRegs r;
-        load_embed_row<TAB_BF16, OVR_BF16>(r, ids, table, slot, ovr, t, H, lane);
+        RowRegs<NC> r;
+        load_embed_row<TAB_BF16, OVR_BF16, NC>(r, ids, table, slot, ovr, t, H, lane);
         float mean, rstd;
         row_stats(r, H, lane, eps, mean, rstd);
         store_norm(r, w, mean, rstd, y32 ? y32 + t * H : nullptr, y16 ? y16 + t * H : nullptr, H, lane);
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
 // Backward of the gather + LayerNorm: LayerNorm backward on the re-gathered row, then the row gradient is
 // scattered: atomically added into d_table[ids[t]] (several tokens share a row) or stored to d_override[slot[t]]
 // (each audio row is used exactly once).
-template <bool TAB_BF16, bool OVR_BF16>
+template <bool TAB_BF16, bool OVR_BF16, int NC>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids,
                                                            const void* __restrict__ table, const int32_t* __restrict__ slot,
                                                            const void* __restrict__ ovr, const float* __restrict__ w,
@@ -239,17 +244,17 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
     const int wid = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    RowRegs dw;
+    RowRegs<NC> dw;
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int64_t t = wave; t < T; t += nwaves) {
-        RowRegs xr, gr;
-        load_embed_row<TAB_BF16, OVR_BF16>(xr, ids, table, slot, ovr, t, H, lane);
-        load_row<false>(gr, dy + t * H, H, lane);
+        RowRegs<NC> xr, gr;
+        load_embed_row<TAB_BF16, OVR_BF16, NC>(xr, ids, table, slot, ovr, t, H, lane);
+        load_row<false, NC>(gr, dy + t * H, H, lane);
         const float mean = mean_in[t], rstd = rstd_in[t];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H) {
                 const f32x4 xhat = (xr.v[c] - mean) * rstd;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
         float* dst = s >= 0 ? (d_ovr ? d_ovr + (int64_t)s * H : nullptr)
                             : ((d_table && id != padding_idx) ? d_table + id * H : nullptr);
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H && dst) {
                 const f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
         }
     }
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) *reinterpret_cast<f32x4*>(dw_lds + wid * H + col) = dw.v[c];
     }
@@ -327,6 +332,17 @@ __global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __rest
     if (threadIdx.x == 0) count[0] = carry;
 }
 
+// run MACRO(NC) with NC = the smallest supported chunk count covering H
+#define CM3P_NC_SWITCH(H, MACRO)      \
+    {                                 \
+        const int nc__ = ((H) + 255) / 256; \
+        if (nc__ <= 1) { MACRO(1) }   \
+        else if (nc__ == 2) { MACRO(2) } \
+        else if (nc__ == 3) { MACRO(3) } \
+        else if (nc__ == 4) { MACRO(4) } \
+        else { MACRO(8) }             \
+    }
+
 inline int ln_grid(int64_t rows, int cap = 2048) {
     int64_t blocks = (rows + 3) / 4;
     if (blocks > cap) blocks = cap;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -345,10 +361,13 @@ int cm3p_layernorm_fwd(const void* x, int x_dtype, const float* weight, float* y
     CM3P_REQUIRE(x_dtype == CM3P_F32 || x_dtype == CM3P_BF16);
     if (rows == 0) return CM3P_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (x_dtype == CM3P_BF16)
-        layernorm_fwd_kernel<true><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
-    else
-        layernorm_fwd_kernel<false><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
+#define CM3P_LN_FWD(NC)                                                                                                      \
+    if (x_dtype == CM3P_BF16)                                                                                                \
+        layernorm_fwd_kernel<true, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps); \
+    else                                                                                                                     \
+        layernorm_fwd_kernel<false, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
+    CM3P_NC_SWITCH(H, CM3P_LN_FWD)
+#undef CM3P_LN_FWD
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -364,10 +383,13 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = ln_bwd_grid(rows);
     const size_t lds = (size_t)4 * H * sizeof(float);
-    if (dy_dtype == CM3P_BF16)
-        layernorm_bwd_kernel<true><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
-    else
-        layernorm_bwd_kernel<false><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
+#define CM3P_LN_BWD(NC)                                                                                                      \
+    if (dy_dtype == CM3P_BF16)                                                                                               \
+        layernorm_bwd_kernel<true, NC><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H); \
+    else                                                                                                                     \
+        layernorm_bwd_kernel<false, NC><<<grid, 256, lds, s>>>(dy, x, weight, mean, rstd, dres, dx_f32, (uint16_t*)dx_bf16, dw_partial, rows, H);
+    CM3P_NC_SWITCH(H, CM3P_LN_BWD)
+#undef CM3P_LN_BWD
     CM3P_LAUNCH_CHECK();
     colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
@@ -383,14 +405,19 @@ int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = ln_grid(T);
     const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
-#define CM3P_EMB_FWD(TB, OB)                                                                                           \
-    embed_ln_fwd_kernel<TB, OB><<<grid, 256, 0, s>>>(ids, table, slot, override_rows, weight, y_f32, (uint16_t*)y_bf16, \
-                                                     mean, rstd, T, H, eps)
+#define CM3P_EMB_FWD_NC(NC) \
+    embed_ln_fwd_kernel<TB_, OB_, NC><<<grid, 256, 0, s>>>(ids, table, slot, override_rows, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, T, H, eps);
+#define CM3P_EMB_FWD(TB, OB)               \
+    do {                                   \
+        constexpr bool TB_ = TB, OB_ = OB; \
+        CM3P_NC_SWITCH(H, CM3P_EMB_FWD_NC) \
+    } while (0)
     if (tb && ob) CM3P_EMB_FWD(true, true);
     else if (tb) CM3P_EMB_FWD(true, false);
     else if (ob) CM3P_EMB_FWD(false, true);
     else CM3P_EMB_FWD(false, false);
 #undef CM3P_EMB_FWD
+#undef CM3P_EMB_FWD_NC
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -405,14 +432,20 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
     const int grid = ln_bwd_grid(T);
     const size_t lds = (size_t)4 * H * sizeof(float);
     const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
-#define CM3P_EMB_BWD(TB, OB)                                                                                          \
-    embed_ln_bwd_kernel<TB, OB><<<grid, 256, lds, s>>>(dy, ids, table, slot, override_rows, weight, mean, rstd, d_table, \
-                                                       d_override, dw_partial, T, H, padding_idx)
+#define CM3P_EMB_BWD_NC(NC)                                                                                              \
+    embed_ln_bwd_kernel<TB_, OB_, NC><<<grid, 256, lds, s>>>(dy, ids, table, slot, override_rows, weight, mean, rstd, d_table, \
+                                                             d_override, dw_partial, T, H, padding_idx);
+#define CM3P_EMB_BWD(TB, OB)               \
+    do {                                   \
+        constexpr bool TB_ = TB, OB_ = OB; \
+        CM3P_NC_SWITCH(H, CM3P_EMB_BWD_NC) \
+    } while (0)
     if (tb && ob) CM3P_EMB_BWD(true, true);
     else if (tb) CM3P_EMB_BWD(true, false);
     else if (ob) CM3P_EMB_BWD(false, true);
     else CM3P_EMB_BWD(false, false);
 #undef CM3P_EMB_BWD
+#undef CM3P_EMB_BWD_NC
     CM3P_LAUNCH_CHECK();
     colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
