@@ -85,6 +85,14 @@ def _wgrad_splits(M: int, N: int, K: int) -> int:
     return query("cm3p_gemm_wgrad_splits", M, N, K)
 
 
+def _gemm_tag(M: int, N: int, K: int, a_kc, b_kc, epilogue, split_k: int) -> str:
+    """Profiler tag = the kernel the library will pick (same rule as cm3p_gemm_bf16 in csrc/gemm.hip), spelled like rocprof."""
+    kchunk = K if split_k <= 1 else -(-(-(-K // split_k)) // 64) * 64
+    big = K % 64 == 0 and kchunk % 64 == 0 and (-(-M // 256)) * (-(-N // 256)) * max(1, -(-K // kchunk)) >= 200
+    b2s = lambda v: "true" if v else "false"
+    return f"{'gemm256_kernel' if big else 'gemm_bf16_kernel'}<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}>"
+
+
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, epilogue: int,
          resid: Optional[Tensor] = None, out: Optional[Tensor] = None, split_k: int = 1) -> Tensor:
     """C[m,n] = sum_k A(m,k) B(n,k) (+resid).  a/b bf16, row-major 2-D; see include/cm3p_hip.h for the layouts."""
@@ -93,7 +101,7 @@ def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, e
         out = _empty((M, N), torch.bfloat16 if epilogue == EPI_BF16 else torch.float32, a)
     ws = _empty((split_k, M, N), torch.float32, a) if split_k > 1 else None
     call("cm3p_gemm_bf16", ptr(a), ptr(b), ptr(out), ptr(resid), M, N, K, lda, ldb, N, int(a_kc), int(b_kc), epilogue, split_k,
-         ptr(ws), stream(), tag=f"gemm_bf16_kernel<{int(a_kc)},{int(b_kc)},{epilogue}>", work=2.0 * M * N * K)
+         ptr(ws), stream(), tag=_gemm_tag(M, N, K, a_kc, b_kc, epilogue, split_k), work=2.0 * M * N * K)
     return out
 
 
@@ -110,7 +118,8 @@ def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_
     N = w.shape[0]
     out = _empty((T, N), torch.bfloat16, x)
     call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos), ptr(sin), S, int(per_batch), 2 * N // 3, stream(),
-         tag="gemm_bf16_kernel<1,1,rope>", work=2.0 * T * N * Kd)
+         tag=("gemm256_kernel" if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
+         work=2.0 * T * N * Kd)
     return out
 
 
