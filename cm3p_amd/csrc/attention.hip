@@ -16,8 +16,8 @@
 //   dq       recompute S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta); dQ^T += K^T dS^T (K^T by transposed reads).
 //   dk, dv   key on the lane: S = Q K^T, dP = dO V^T with -lse/scale and -delta preloaded as the initial accumulators;
 //            dV^T += dO^T P and dK^T += Q^T dS consume the accumulators directly as B operands.
-// LDS images (128-byte rows): "R" for ds_read_b128 row fragments (16-byte chunk index XOR (row>>1)&7) and "T" for
-// transposed reads (32-byte segment index XOR 2*((row>>1)&1)); both are bank-conflict free for these access shapes.
+// LDS tiles use one swizzled image (128-byte rows) that is bank-conflict free for ds_read_b128 row fragments AND for
+// ds_read_b64_tr_b16 transposed reads, so a tile consumed both ways (K in dq; Q and dO in dk/dv) is stored once.
 #include <limits.h>
 
 #include "common.h"
@@ -27,10 +27,14 @@ namespace {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegInf = -__builtin_huge_valf();
 
-__device__ __forceinline__ int off_R(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ int off_T(int row, int col) {
-    return row * 128 + ((((col >> 4) ^ (((row >> 1) & 1) << 1)) & 3) << 5) + ((col & 15) << 1);
-}
+// ONE LDS image serves both access shapes (128-byte rows of 64 bf16, 16-byte chunk index XOR swz(row)):
+//   row fragments   (ds_read_b128, lane = row, fixed chunk): the 8 even / 8 odd rows of every 16-lane group get 8 different
+//                   swz values -> 16 different 16-byte slots of the 256-byte bank row;
+//   transposed reads (ds_read_b64_tr_b16, 4 rows x 64 bytes per 32-lane half): rows b, b+1 sit in different halves of the
+//                   bank row and bit 2 of swz moves rows b+2, b+3 to the other aligned group of four chunks.
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int off_R(int row, int c16) { return row * 128 + ((c16 ^ swz(row)) << 4); }
+__device__ __forceinline__ int off_T(int row, int col) { return row * 128 + (((col >> 3) ^ swz(row)) << 4) + ((col & 7) << 1); }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -92,13 +96,6 @@ __device__ __forceinline__ void lstore64_R(char* tile, const TileRegs64& t, int 
         *reinterpret_cast<uint4*>(tile + off_R(row, c)) = t.v[i];
     }
 }
-__device__ __forceinline__ void lstore64_T(char* tile, const TileRegs64& t, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-        *reinterpret_cast<uint4*>(tile + off_T(row, c * 8)) = t.v[i];
-    }
-}
 
 __device__ __forceinline__ float reg_max16(const f32x16& a) {  // 8 x v_max3_f32
     const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
@@ -131,7 +128,7 @@ __device__ __forceinline__ bool tile_unmasked(int all_valid, int key0, int q0, i
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward: one workgroup = 4 waves = 128 queries of one (batch, head); K/V tiles of 64 keys, double buffered.
-// LDS per stage: K image R (8 KiB) + V image T (8 KiB) + 64 mask bytes.
+// LDS per stage: K image (8 KiB) + V image (8 KiB) + 64 mask bytes + flag.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask bytes, all-valid flag
 
@@ -203,7 +200,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
     auto lstore = [&](int stage) {
         char* st = smem + stage * kFwdStage;
         lstore64_R(st, kr, tid);
-        lstore64_T(st + 8192, vr, tid);
+        lstore64_R(st + 8192, vr, tid);
         if (tid < 64) {
             reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
             const unsigned long long valid = __ballot(mreg != 0);
@@ -343,9 +340,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// dQ: same geometry as the forward.  LDS per stage: K image R + K image T + V image R + mask bytes.
+// dQ: same geometry as the forward.  LDS per stage: K image (row + transposed reads) + V image + mask bytes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDqStage = 3 * 8192 + 64 + 16;
+constexpr int kDqStage = 2 * 8192 + 64 + 16;  // K image, V image, mask bytes, all-valid flag
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
@@ -407,12 +404,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     auto lstore = [&](int stage) {
         char* st = smem + stage * kDqStage;
         lstore64_R(st, kr, tid);
-        lstore64_T(st + 8192, kr, tid);
-        lstore64_R(st + 16384, vr, tid);
+        lstore64_R(st + 8192, vr, tid);
         if (tid < 64) {
-            reinterpret_cast<uint8_t*>(st + 24576)[tid] = mreg;
+            reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
             const unsigned long long valid = __ballot(mreg != 0);
-            if (tid == 0) *reinterpret_cast<int*>(st + 24640) = (valid == ~0ull) ? 1 : 0;
+            if (tid == 0) *reinterpret_cast<int*>(st + 16448) = (valid == ~0ull) ? 1 : 0;
         }
     };
 
@@ -438,11 +434,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
-                    dp[blk] = mfma32(frag_R(st + 16384, 32 * blk, s, lane), dof[s], dp[blk]);
+                    dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp[blk]);
                 }
             }
-            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 24640), key0, q0, window)) {
-                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 24576);
+            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 16448), key0, q0, window)) {
+                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
                 mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
                 mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
             }
@@ -456,8 +452,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 dsf = acc_to_frag(sacc[s >> 1], s & 1);
-                dq[0] = mfma32(frag_T(st + 8192, 16 * s, 0, lane), dsf, dq[0]);
-                dq[1] = mfma32(frag_T(st + 8192, 16 * s, 1, lane), dsf, dq[1]);
+                dq[0] = mfma32(frag_T(st, 16 * s, 0, lane), dsf, dq[0]);  // K^T from the same image as the row reads
+                dq[1] = mfma32(frag_T(st, 16 * s, 1, lane), dsf, dq[1]);
             }
         }
         if (more) lstore(stage ^ 1);
@@ -495,9 +491,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // ---------------------------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = 4 waves = 128 keys of one (batch, head); each wave owns 32 keys (key on the lane) and keeps
 // dK^T, dV^T (64 x 32 each) in accumulators while the workgroup sweeps query tiles of 64 rows.
-// LDS per stage: Q image R + Q image T + dO image R + dO image T (8 KiB each) + lse/scale and delta (64 floats each).
+// LDS per stage: Q image + dO image (8 KiB each, row and transposed reads) + -lse*log2(e) and -delta (64 floats each).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDkvStage = 4 * 8192 + 512;
+constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, -lse*log2e and -delta rows
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
@@ -561,10 +557,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     auto lstore = [&](int stage) {
         char* st = smem + stage * kDkvStage;
         lstore64_R(st, qr, tid);
-        lstore64_T(st + 8192, qr, tid);
-        lstore64_R(st + 16384, gr, tid);
-        lstore64_T(st + 24576, gr, tid);
-        if (tid < 128) reinterpret_cast<float*>(st + 32768)[tid] = sreg;
+        lstore64_R(st + 8192, gr, tid);
+        if (tid < 128) reinterpret_cast<float*>(st + 16384)[tid] = sreg;
     };
 
     gload(t_lo);
@@ -578,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         if (more) gload(t + 1);
         const int qt0 = t * 64;
         if (wave_live && qt0 <= whi && qt0 + 63 >= wlo) {
-            const float* nlse = reinterpret_cast<const float*>(st + 32768);
+            const float* nlse = reinterpret_cast<const float*>(st + 16384);
             const float* ndlt = nlse + 64;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {  // two 32-query blocks of the tile
@@ -597,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);           // log2 p: rows q, col key
-                    dp = mfma32(frag_R(st + 16384, 32 * qb, s, lane), vf[s], dp);       // dP - delta
+                    dp = mfma32(frag_R(st + 8192, 32 * qb, s, lane), vf[s], dp);        // dP - delta
                 }
                 // every (query, key) pair of this 32 x 32 block visible?  (queries past S carry -inf and give p = 0 anyway)
                 const int qb0 = qt0 + 32 * qb;
@@ -627,10 +621,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                     const bf16x8 pf = acc_to_frag(sacc, sp);
                     const bf16x8 dsf = acc_to_frag(dp, sp);
                     const int r0 = 32 * qb + 16 * sp;
-                    dv[0] = mfma32(frag_T(st + 24576, r0, 0, lane), pf, dv[0]);
-                    dv[1] = mfma32(frag_T(st + 24576, r0, 1, lane), pf, dv[1]);
-                    dk[0] = mfma32(frag_T(st + 8192, r0, 0, lane), dsf, dk[0]);
-                    dk[1] = mfma32(frag_T(st + 8192, r0, 1, lane), dsf, dk[1]);
+                    dv[0] = mfma32(frag_T(st + 8192, r0, 0, lane), pf, dv[0]);  // dO^T and Q^T from the row-read images
+                    dv[1] = mfma32(frag_T(st + 8192, r0, 1, lane), pf, dv[1]);
+                    dk[0] = mfma32(frag_T(st, r0, 0, lane), dsf, dk[0]);
+                    dk[1] = mfma32(frag_T(st, r0, 1, lane), dsf, dk[1]);
                 }
             }
         }
