@@ -2,7 +2,7 @@
 
 The reference never gathers: under DDP every rank contrasts only its own pairs.  With
 `model.gather_negatives = True` each rank all-gathers the L2-normalised (b, P) beatmap and metadata embeddings of every
-rank (one fused (b, 2, P) fp32 buffer; RCCL over xGMI on GPUs, gloo in the CPU tests), scores its b rows against all
+rank (one fused (b, 2, P) fp32 buffer; RCCL over xGMI on GPUs, gloo in the tests), scores its b rows against all
 N*b columns in both directions, and takes the cross-entropy with targets r*b + i.  Parity definition: with DDP's
 gradient averaging the parameter gradients equal those of the single-process loss on the concatenated N*b batch, and
 the mean of the per-rank losses equals that loss.
@@ -47,35 +47,15 @@ class AllGatherEmbeds(torch.autograd.Function):
         return out, None
 
 
-def gather_pair(metadata_embeds: Tensor, beatmap_embeds: Tensor, group=None, side_stream=None):
+def gather_pair(metadata_embeds: Tensor, beatmap_embeds: Tensor, group=None):
     """One collective for both modalities: (b, P), (b, P) -> (N*b, P), (N*b, P).
 
-    On GPUs the collective is issued on `side_stream` (a HIP stream next to the compute stream) and joined before the
-    logits need it, so the copy into the fused buffer and RCCL's launch do not serialise the compute stream."""
-    b, P = metadata_embeds.shape
-    if side_stream is not None and metadata_embeds.is_cuda:
-        cur = torch.cuda.current_stream()
-        side_stream.wait_stream(cur)
-        with torch.cuda.stream(side_stream):
-            fused = torch.stack((metadata_embeds, beatmap_embeds), dim=1)  # (b, 2, P): layout only, no arithmetic
-            allf = AllGatherEmbeds.apply(fused, group)
-        cur.wait_stream(side_stream)
-    else:
-        fused = torch.stack((metadata_embeds, beatmap_embeds), dim=1)
-        allf = AllGatherEmbeds.apply(fused, group)
+    The fused buffer is 2*b*P fp32 (128 KiB at b = 32): latency-bound, a few tens of microseconds on RCCL, and the
+    logits need it immediately, so it is issued on the compute stream (a side stream would buy nothing here and would
+    need cross-stream allocator bookkeeping)."""
+    fused = torch.stack((metadata_embeds, beatmap_embeds), dim=1)  # (b, 2, P): layout only, no arithmetic
+    allf = AllGatherEmbeds.apply(fused, group)
     return allf[:, 0].contiguous(), allf[:, 1].contiguous()
-
-
-_SIDE = {}
-
-
-def _side_stream(device):
-    if device.type != "cuda":
-        return None
-    key = device.index
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
 
 
 def gathered_contrastive(metadata_embeds: Tensor, beatmap_embeds: Tensor, logit_scale: Tensor, group=None):
@@ -84,7 +64,7 @@ def gathered_contrastive(metadata_embeds: Tensor, beatmap_embeds: Tensor, logit_
 
     r = dist.get_rank(group)
     b = metadata_embeds.shape[0]
-    m_all, b_all = gather_pair(metadata_embeds, beatmap_embeds, group, _side_stream(metadata_embeds.device))
+    m_all, b_all = gather_pair(metadata_embeds, beatmap_embeds, group)
     lpm = _LogitsFn.apply(metadata_embeds, b_all, logit_scale)  # this rank's metadata rows vs every beatmap
     lpb = _LogitsFn.apply(beatmap_embeds, m_all, logit_scale)   # this rank's beatmap rows vs every metadata
     n = lpm.shape[1]
