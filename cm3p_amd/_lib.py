@@ -55,6 +55,11 @@ SIGNATURES = {
     "cm3p_l2norm_fwd": [_P, _P, _P, _I, _I, _P],
     "cm3p_l2norm_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "cm3p_cross_entropy": [_P, _I, _I, _L, _L, _P, _P, _F, _P, _P, _P],
+    "cm3p_cross_entropy_masked": [_P, _L, _I, _L, _P, _L, _F, _P, _P, _P, _P],
+    "cm3p_inv_valid_count": [_P, _L, _L, _P, _P],
+    "cm3p_add_bias_f32": [_P, _P, _L, _I, _P],
+    "cm3p_colsum_blocks": [_L],
+    "cm3p_colsum_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_first_zero_index": [_P, _I, _I, _P, _P],
     "cm3p_scale_exp": [_P, _P, _P, _L, _P],
     "cm3p_scale_by": [_P, _P, _P, _L, _P],

@@ -93,6 +93,73 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     }
 }
 
+// Masked-LM cross entropy (nn.functional.cross_entropy(ignore_index=...) as used by ForMaskedLMLoss,
+// TF:loss/loss_utils.py:32-46,74-91): rows whose target equals ignore_index contribute nothing.  dlogits (same layout,
+// fully written) = grad_scale * (*inv_count) * (softmax - onehot), zero for ignored rows and for padded columns.
+__global__ __launch_bounds__(256) void cross_entropy_masked_kernel(const float* __restrict__ logits, int cols, int64_t row_stride,
+                                                                   const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                   float grad_scale, const float* __restrict__ inv_count,
+                                                                   float* __restrict__ loss_rows, float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const float* x = logits + (int64_t)r * row_stride;
+    float* d = dlogits ? dlogits + (int64_t)r * row_stride : nullptr;
+    const int64_t t = target[r];
+    if (t == ignore_index) {  // block-uniform
+        if (threadIdx.x == 0) loss_rows[r] = 0.f;
+        if (d)
+            for (int c = threadIdx.x; c < row_stride; c += 256) d[c] = 0.f;
+        return;
+    }
+    float mx = -__builtin_huge_valf();
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, x[c]);
+    mx = block_reduce(mx, red, true);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) se += expf(x[c] - mx);
+    se = block_reduce(se, red, false);
+    const float lse = mx + logf(se);
+    if (threadIdx.x == 0) loss_rows[r] = lse - x[t];
+    if (d) {
+        const float g = grad_scale * inv_count[0];
+        for (int c = threadIdx.x; c < row_stride; c += 256) d[c] = c < cols ? g * (expf(x[c] - lse) - (c == t ? 1.0f : 0.0f)) : 0.f;
+    }
+}
+
+// inv_count[0] = 1 / max(#targets != ignore_index, 1)   (the "mean" reduction's denominator)
+__global__ __launch_bounds__(256) void inv_valid_count_kernel(const int64_t* __restrict__ target, int64_t n, int64_t ignore_index,
+                                                              float* __restrict__ inv_count) {
+    __shared__ float red[4];
+    float c = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) c += target[i] != ignore_index ? 1.f : 0.f;
+    c = block_reduce(c, red, false);
+    if (threadIdx.x == 0) inv_count[0] = 1.0f / fmaxf(c, 1.0f);
+}
+
+// x[r, c] += bias[c]
+__global__ __launch_bounds__(256) void add_bias_kernel(float* __restrict__ x, const float* __restrict__ bias, int64_t rows, int cols4) {
+    const int64_t total = rows * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cols4);
+        reinterpret_cast<f32x4*>(x)[i] += reinterpret_cast<const f32x4*>(bias)[c];
+    }
+}
+
+// partial[b, c] = sum over rows r = b, b + nblk, ... of x[r, c]; then out[c] = sum_b partial[b, c] (fixed order)
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows, int cols) {
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float acc = 0.f;
+        for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) acc += x[r * cols + c];
+        partial[(int64_t)blockIdx.x * cols + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * cols + c];
+    out[c] = s;
+}
+
 __global__ void first_zero_index_kernel(const int64_t* __restrict__ classes, int B, int V, int64_t* __restrict__ idx) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -172,6 +239,45 @@ int cm3p_cross_entropy(const float* logits, int rows, int cols, int64_t row_stri
     CM3P_REQUIRE(logits && target && loss_rows && rows > 0 && cols > 0);
     cross_entropy_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(logits, cols, row_stride, col_stride, row_offset,
                                                                             target, grad_scale, loss_rows, dlogits);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_cross_entropy_masked(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target,
+                              int64_t ignore_index, float grad_scale, const float* inv_count, float* loss_rows, float* dlogits,
+                              void* stream) {
+    CM3P_REQUIRE(logits && target && loss_rows && rows > 0 && cols > 0 && row_stride >= cols && (!dlogits || inv_count));
+    cross_entropy_masked_kernel<<<(unsigned)rows, 256, 0, static_cast<hipStream_t>(stream)>>>(logits, cols, row_stride, target, ignore_index,
+                                                                                             grad_scale, inv_count, loss_rows, dlogits);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index, float* inv_count, void* stream) {
+    CM3P_REQUIRE(target && inv_count && n > 0);
+    inv_valid_count_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(target, n, ignore_index, inv_count);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_add_bias_f32(float* x, const float* bias, int64_t rows, int cols, void* stream) {
+    CM3P_REQUIRE(x && bias && rows > 0 && cols > 0 && cols % 4 == 0);
+    int64_t blocks = (rows * (cols / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    add_bias_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, rows, cols / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_colsum_blocks(int64_t rows) { return (int)(rows < 512 ? (rows < 1 ? 1 : rows) : 512); }
+
+int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, int cols, void* stream) {
+    CM3P_REQUIRE(x && partial && out && rows > 0 && cols > 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = cm3p_colsum_blocks(rows);
+    colsum_rows_kernel<<<nblk, 256, 0, s>>>(x, partial, rows, cols);
+    CM3P_LAUNCH_CHECK();
+    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, s>>>(partial, out, nblk, cols);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -292,6 +292,35 @@ def cross_entropy(logits: Tensor, rows: int, cols: int, row_stride: int, col_str
     return loss_rows
 
 
+def cross_entropy_masked(logits: Tensor, cols: int, target: Tensor, ignore_index: int, grad_scale: float, inv_count: Tensor,
+                         want_grad: bool):
+    rows, pitch = logits.shape
+    loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    call("cm3p_cross_entropy_masked", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, grad_scale, ptr(inv_count),
+         ptr(loss_rows), ptr(dlogits), stream())
+    return loss_rows, dlogits
+
+
+def inv_valid_count(target: Tensor, ignore_index: int) -> Tensor:
+    out = torch.empty((1,), dtype=torch.float32, device=target.device)
+    call("cm3p_inv_valid_count", ptr(target), target.numel(), ignore_index, ptr(out), stream())
+    return out
+
+
+def add_bias_(x: Tensor, bias: Tensor) -> Tensor:
+    call("cm3p_add_bias_f32", ptr(x), ptr(bias), x.shape[0], x.shape[1], stream())
+    return x
+
+
+def colsum_f32(x: Tensor) -> Tensor:
+    rows, cols = x.shape
+    part = torch.empty((query("cm3p_colsum_blocks", rows), cols), dtype=torch.float32, device=x.device)
+    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    call("cm3p_colsum_f32", ptr(x), ptr(part), ptr(out), rows, cols, stream())
+    return out
+
+
 def first_zero_index(classes: Tensor) -> Tensor:
     B, V = classes.shape
     idx = torch.empty((B,), dtype=torch.int64, device=classes.device)

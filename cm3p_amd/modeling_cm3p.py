@@ -6,9 +6,10 @@ submodule / state-dict names and Auto* registration, so `train.py` drives it unc
 All arithmetic runs in libcm3p_hip.so through autograd nodes defined here and in encoder.py; there is no PyTorch-op
 fallback and inputs must live on the GPU.
 
-Scope: CM3PModel's contrastive branch with both towers and the audio front end.  The MLM / classifier
-heads (`CM3PForMaskedLM`, `CM3PForBeatmapClassification`, `has_decoder_head`) are later rows: importable, but they
-raise NotImplementedError when constructed.
+Scope: CM3PModel's contrastive branch with both towers and the audio front end, plus the first "next"
+row: CM3PModel's MLM head (`has_decoder_head`, loss_type "ForMaskedLM": `loss += 0.5 * mlm_loss`, the v7 recipe).  The
+stand-alone variants (`CM3PForMaskedLM`, `CM3PForBeatmapClassification`, `*WithProjection`) are later rows: importable,
+but they raise NotImplementedError when constructed.
 """
 from __future__ import annotations
 
@@ -197,6 +198,98 @@ def cm3p_loss_hip(logits_per_metadata: Tensor, metadata_variation_classes: Optio
     return _CrossEntropySumFn.apply(specs, L)
 
 
+class _MLMHeadFn(torch.autograd.Function):
+    """decoder(norm(gelu(dense(h)))) (CM3PPredictionHead + decoder, ref:cm3p/modeling_cm3p.py:991,1229-1238) -> fp32
+    logits [T, Vp], Vp = vocab rounded up to a multiple of 8 (pad columns hold the zero pad weights' product; callers slice)."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, Wd: Tensor, bd: Optional[Tensor], norm_w: Tensor, Wdec: Tensor, bdec: Optional[Tensor], eps: float):
+        from ._lib import EPI_F32
+        from .encoder import _bf16_weight
+
+        T, H = h.shape
+        V = Wdec.shape[0]
+        Vp = (V + 7) // 8 * 8
+        hb = K.cast_bf16(h.detach().contiguous())
+        Wd_b = _bf16_weight(Wd)
+        Wdec_b = _bf16_weight(Wdec)
+        if Vp != V:
+            pad = torch.zeros((Vp, H), dtype=torch.bfloat16, device=h.device)
+            pad[:V].copy_(Wdec_b)  # layout only: pad the vocabulary to the GEMM's column granularity
+            Wdec_b = pad
+        bd32 = _f32(bd.detach()).contiguous() if bd is not None else torch.zeros((H,), dtype=torch.float32, device=h.device)
+        w32 = _f32(norm_w.detach()).contiguous()
+        z = K.gemm(hb, Wd_b, T, H, H, True, True, EPI_F32)
+        _, a32 = K.bias_gelu_fwd(z, bd32, False, True)
+        _, y, mean, rstd = K.layernorm_fwd(a32, w32, eps, False, True)
+        logits = K.gemm(y, Wdec_b, T, Vp, H, True, True, EPI_F32)
+        if bdec is not None:
+            bp = torch.zeros((Vp,), dtype=torch.float32, device=h.device)
+            bp[:V].copy_(_f32(bdec.detach()))
+            K.add_bias_(logits, bp)
+        ctx.pack = (hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V)
+        ctx.meta = (Wd.dtype, bd.dtype if bd is not None else None, norm_w.dtype, Wdec.dtype, bdec.dtype if bdec is not None else None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl: Tensor):
+        from ._lib import EPI_F32
+
+        hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V = ctx.pack
+        dWd_t, dbd_t, dnw_t, dWdec_t, dbdec_t = ctx.meta
+        dl = dl.contiguous()
+        T, H = hb.shape
+        dlb = K.cast_bf16(dl)
+        dy = K.linear_dgrad(dlb, Wdec_b)
+        dWdec = K.linear_wgrad(dlb, y)[:V]
+        dbdec = K.colsum_f32(dl)[:V] if dbdec_t is not None else None
+        da, _, dnw = K.layernorm_bwd(dy, a32, w32, mean, rstd, None, False, inplace=False)
+        dz, dbd = K.bias_gelu_bwd(da, z, bd32)
+        dh = K.gemm(dz, Wd_b, T, H, H, True, False, EPI_F32) if ctx.needs_input_grad[0] else None
+        dWd = K.linear_wgrad(dz, hb)
+        return (dh, dWd.to(dWd_t), dbd.to(dbd_t) if dbd_t is not None else None, dnw.to(dnw_t), dWdec.to(dWdec_t),
+                dbdec.to(dbdec_t) if dbdec is not None else None, None)
+
+
+class _MaskedLMLossFn(torch.autograd.Function):
+    """ForMaskedLMLoss (TF:loss/loss_utils.py:32-46,74-91): mean cross entropy over labels != -100, or the sum divided by
+    `num_items_in_batch` when the Trainer supplies it.  logits: fp32 [T, Vp] with `vocab` live columns."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, labels: Tensor, vocab: int, num_items: Optional[Tensor]):
+        lab = labels.reshape(-1).contiguous().to(torch.int64)
+        if num_items is None:
+            inv = K.inv_valid_count(lab, -100)
+        else:
+            n = num_items if torch.is_tensor(num_items) else torch.tensor(float(num_items))
+            inv = (1.0 / n.to(device=logits.device, dtype=torch.float32)).reshape(1).contiguous()  # scalar plumbing
+        lr, dlog = K.cross_entropy_masked(logits.detach().contiguous(), vocab, lab, -100, 1.0, inv, True)
+        loss = K.scale_by(K.sum_f32(lr, 1.0), inv)
+        ctx.dlog = dlog
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return K.scale_by(ctx.dlog, g.reshape(1).contiguous()), None, None, None
+
+
+class _AddScaledFn(torch.autograd.Function):
+    """a + c * b for 0-dim fp32 tensors on the device (`loss += 0.5 * mlm_loss`, ref:cm3p/modeling_cm3p.py:996)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, c: float):
+        ctx.c = c
+        out = a.detach().reshape(1).clone()
+        K.sum_f32(b.detach().reshape(1).contiguous(), c, out=out, accumulate=True)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        gc = torch.empty((1,), dtype=torch.float32, device=g.device)
+        K.sum_f32(g.reshape(1).contiguous(), ctx.c, out=gc)
+        return g, gc.reshape(()), None
+
+
 # ----------------------------------------------------------------------------------------------- base class
 class CM3PPreTrainedModel(PreTrainedModel):
     config_class = CM3PConfig
@@ -361,6 +454,17 @@ class CM3PBeatmapTransformer(nn.Module):
                                       audio_model_output=audio_out)
 
 
+class CM3PPredictionHead(nn.Module):
+    """Parameter container of the MLM head (ref:cm3p/modeling_cm3p.py:1229-1238): dense -> GELU -> LayerNorm."""
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__()
+        if config.classifier_activation != "gelu" or config.norm_bias:
+            raise NotImplementedError("MLM head: classifier_activation must be 'gelu' and norm_bias False")
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size, config.classifier_bias)
+        self.norm = nn.LayerNorm(config.hidden_size, eps=config.norm_eps, bias=False)
+
+
 class CM3PMetadataModel(CM3PPreTrainedModel):
     config_class = CM3PMetadataConfig
 
@@ -408,8 +512,10 @@ class CM3PModel(CM3PPreTrainedModel):
             raise TypeError(f"config.metadata_config is expected to be of type CM3PMetadataConfig but is of type {type(config.metadata_config)}.")
         if not isinstance(config.beatmap_config, CM3PBeatmapConfig):
             raise TypeError(f"config.beatmap_config is expected to be of type CM3PBeatmapConfig but is of type {type(config.beatmap_config)}.")
-        if config.has_decoder_head:
-            raise NotImplementedError("has_decoder_head (MLM head + 0.5*mlm_loss) is a later row of SURVEY.md §8(f); not in this build")
+        if config.has_decoder_head and config.loss_type != "ForMaskedLM":
+            # the reference silently falls back to a shifted causal-LM loss for any other value (TF:modeling_utils.py:4655-4667)
+            raise NotImplementedError('has_decoder_head needs loss_type="ForMaskedLM" (the published v7 recipe)')
+        self.loss_type = config.loss_type
         self.projection_dim = config.projection_dim
         self.metadata_embed_dim = config.metadata_config.hidden_size
         self.beatmap_embed_dim = config.beatmap_config.hidden_size
@@ -418,6 +524,10 @@ class CM3PModel(CM3PPreTrainedModel):
         self.beatmap_projection = nn.Linear(self.beatmap_embed_dim, self.projection_dim, bias=False)
         self.metadata_projection = nn.Linear(self.metadata_embed_dim, self.projection_dim, bias=False)
         self.logit_scale = nn.Parameter(torch.tensor(float(config.logit_scale_init_value)))
+        if config.has_decoder_head:  # MLM head on the beatmap tower (ref:cm3p/modeling_cm3p.py:765-767)
+            bc = config.beatmap_config
+            self.head = CM3PPredictionHead(bc)
+            self.decoder = nn.Linear(bc.hidden_size, bc.vocab_size, bias=bc.decoder_bias)
         # Opt-in: in-batch negatives across all ranks of the default process group (new behaviour).
         self.gather_negatives = False
         self.post_init()
@@ -500,8 +610,25 @@ class CM3PModel(CM3PPreTrainedModel):
                 if return_loss:
                     loss = cm3p_loss_hip(logits_per_metadata, metadata_variation_classes)
 
+        logits = None
+        if output_logits:  # MLM head; with labels, loss += 0.5 * masked-LM loss (ref:cm3p/modeling_cm3p.py:987-996)
+            if beatmap_outputs is None:
+                raise ValueError("output_logits needs input_ids")
+            hs = beatmap_outputs.last_hidden_state
+            Bq, Sq, Hq = hs.shape
+            V = self.config.beatmap_config.vocab_size
+            lp = _MLMHeadFn.apply(hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
+                                  self.decoder.weight, self.decoder.bias, self.config.beatmap_config.norm_eps)
+            logits = lp.view(Bq, Sq, -1)[..., :V]
+            if labels is not None and return_loss:
+                mlm = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))
+                if torch.is_tensor(loss):
+                    loss = _AddScaledFn.apply(loss, mlm, 0.5)
+                else:
+                    loss = _AddScaledFn.apply(torch.zeros((), dtype=torch.float32, device=mlm.device), mlm, 0.5)
+
         return CM3POutput(loss=loss, logits_per_beatmap=logits_per_beatmap, logits_per_metadata=logits_per_metadata,
-                          metadata_embeds=metadata_embeds, beatmap_embeds=beatmap_embeds, logits=None,
+                          metadata_embeds=metadata_embeds, beatmap_embeds=beatmap_embeds, logits=logits,
                           metadata_model_output=metadata_outputs, beatmap_model_output=beatmap_outputs)
 
 

@@ -207,6 +207,22 @@ int cm3p_scale_by(const float* x, const float* scale, float* y, int64_t n, void*
 int cm3p_dot_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* out[0] (+)= scale * sum x[i] (fixed order): the mean over rows inside cross_entropy and the /2 of cm3p_loss. */
 int cm3p_sum_f32(const float* x, float* out, int64_t n, float scale, int accumulate, void* stream);
+/* Masked-LM head (CM3PPredictionHead + decoder + ForMaskedLMLoss; ref:cm3p/modeling_cm3p.py:987-996,1229-1238,
+ * TF:loss/loss_utils.py:32-46,74-91) - the pieces the encoder kernels do not already cover:
+ * cm3p_cross_entropy_masked: cross_entropy(ignore_index) over contiguous rows of `cols` logits with row pitch
+ *   row_stride (>= cols; the pad columns get zero gradient).  loss_rows[r] = 0 for ignored rows.  dlogits (may be NULL) is
+ *   fully written: grad_scale * inv_count[0] * (softmax - onehot).
+ * cm3p_inv_valid_count: inv_count[0] = 1 / max(#(target != ignore_index), 1) - the "mean" denominator, kept on the device.
+ * cm3p_add_bias_f32: x[r, :] += bias (cols % 4 == 0).   cm3p_colsum_f32: out[c] = sum_r x[r, c] (fixed order; partial is a
+ *   [cm3p_colsum_blocks(rows), cols] workspace) - the decoder bias gradient. */
+int cm3p_cross_entropy_masked(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target,
+                              int64_t ignore_index, float grad_scale, const float* inv_count, float* loss_rows, float* dlogits,
+                              void* stream);
+int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index, float* inv_count, void* stream);
+int cm3p_add_bias_f32(float* x, const float* bias, int64_t rows, int cols, void* stream);
+int cm3p_colsum_blocks(int64_t rows);
+int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, int cols, void* stream);
+
 /* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
 int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);
 

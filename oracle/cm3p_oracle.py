@@ -287,9 +287,24 @@ def contrastive_head(sd: dict, beatmap_pooled: Tensor, metadata_pooled: Tensor,
     return dict(loss=loss, logits_per_metadata=logits_per_metadata, metadata_embeds=me, beatmap_embeds=be)
 
 
+def mlm_head(sd: dict, cfg: dict, last_hidden_state: Tensor) -> Tensor:
+    """decoder(head(h)): dense -> GELU -> LayerNorm(no bias) -> Linear(+bias) (ref:cm3p/modeling_cm3p.py:991,1229-1238)."""
+    h = F.linear(last_hidden_state, sd["head.dense.weight"], sd.get("head.dense.bias"))
+    h = layer_norm(F.gelu(h), sd["head.norm.weight"], cfg["norm_eps"])
+    return F.linear(h, sd["decoder.weight"], sd.get("decoder.bias"))
+
+
+def masked_lm_loss(logits: Tensor, labels: Tensor, vocab_size: int, num_items_in_batch=None) -> Tensor:
+    """ForMaskedLMLoss (TF:loss/loss_utils.py:32-46,74-91)."""
+    lg, lb = logits.float().view(-1, vocab_size), labels.view(-1)
+    if num_items_in_batch is None:
+        return F.cross_entropy(lg, lb, ignore_index=-100, reduction="mean")
+    return F.cross_entropy(lg, lb, ignore_index=-100, reduction="sum") / num_items_in_batch
+
+
 def forward(sd: dict, cfg: dict, *, input_ids: Tensor, metadata_ids: Tensor, attention_mask: Optional[Tensor] = None,
             metadata_attention_mask: Optional[Tensor] = None, input_features: Optional[Tensor] = None,
-            metadata_variation_classes: Optional[Tensor] = None, eager: bool = False,
+            metadata_variation_classes: Optional[Tensor] = None, labels: Optional[Tensor] = None, eager: bool = False,
             collect: Optional[list] = None) -> dict:
     """CM3PModel.forward, contrastive branch (ref:cm3p/modeling_cm3p.py:849-1012)."""
     cfg = resolve_config(cfg)
@@ -303,6 +318,11 @@ def forward(sd: dict, cfg: dict, *, input_ids: Tensor, metadata_ids: Tensor, att
     out["logits_per_beatmap"] = lpm.permute(2, 0, 1) if lpm.dim() == 3 else lpm.t()
     out.update(beatmap_last_hidden_state=bh, beatmap_pooler_output=bp, metadata_last_hidden_state=mh,
                metadata_pooler_output=mp, audio_embeds=audio_embeds)
+    if "decoder.weight" in sd:  # has_decoder_head: logits + 0.5 * masked-LM loss (ref:cm3p/modeling_cm3p.py:987-996)
+        out["logits"] = mlm_head(sd, cfg["beatmap_config"], bh)
+        if labels is not None:
+            out["mlm_loss"] = masked_lm_loss(out["logits"], labels, cfg["beatmap_config"]["vocab_size"])
+            out["loss"] = out["loss"] + 0.5 * out["mlm_loss"]
     return out
 
 

@@ -83,6 +83,11 @@ CASES = {
         cfg=_cfg(_BEATMAP_D64, _METADATA_D64, metadata_config__cls_embed=False),
         B=4, S=256, L=24, pad=True, V=3,
     ),
+    # MLM head: has_decoder_head + loss_type "ForMaskedLM" (the v7 recipe), labels = ids at ~15 % of the positions, else -100
+    "d64_mlm": dict(
+        cfg=dict(_cfg(_BEATMAP_D64, _METADATA_D64, beatmap_config__cls_embed=False), has_decoder_head=True, loss_type="ForMaskedLM"),
+        B=3, S=160, L=16, pad=True, mlm=True,
+    ),
     # audio-fused: input_features (B, n_mels, T) with T/8 placeholders per row
     "d64_audio": dict(cfg=_cfg(_BEATMAP_D64, _METADATA_D64), B=3, S=256, L=16, pad=True, audio_T=320),
 }
@@ -121,6 +126,11 @@ def make_inputs(name: str) -> dict[str, torch.Tensor]:
 
     out["input_ids"] = ids
     out["attention_mask"] = mask
+
+    if case.get("mlm"):
+        pick = (torch.rand(B, S, generator=g) < 0.15) & mask.bool()
+        pick[0, 1] = True  # at least one label
+        out["labels"] = torch.where(pick, ids, torch.full_like(ids, -100))
 
     V = case.get("V")
     mshape = (B, V, L) if V else (B, L)

@@ -122,7 +122,8 @@ def main():
         else:
             # same seed + same shapes -> same weights regardless of cls_embed
             for k, v in model.state_dict().items():
-                assert torch.equal(v, models[arch][k]), k
+                if k in models[arch]:
+                    assert torch.equal(v, models[arch][k]), k
 
         inputs = make_inputs(name)
         hiddens = {}
@@ -142,6 +143,10 @@ def main():
             h.remove()
 
         blob = {f"in.{k}": v.contiguous() for k, v in inputs.items()}
+        extra = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items() if k not in models[arch]}
+        blob.update({f"w.{k}": v for k, v in extra.items()})  # parameters this case adds to the shared weights (MLM head)
+        if out.logits is not None:
+            blob["logits"] = out.logits.detach().contiguous()
         blob["loss"] = out.loss.detach().reshape(1)
         blob["logits_per_metadata"] = out.logits_per_metadata.detach().contiguous()
         blob["metadata_embeds"] = out.metadata_embeds.detach().contiguous()
@@ -157,6 +162,7 @@ def main():
         blob.update(hiddens)
         params = dict(model.named_parameters())
         keys = GRAD_KEYS + (AUDIO_GRAD_KEYS if "input_features" in inputs else [])
+        keys = keys + [k for k in ("head.dense.weight", "head.norm.weight", "decoder.weight", "decoder.bias") if k in params]
         for k in keys:
             if k in params and params[k].grad is not None:
                 blob[f"grad.{k}"] = params[k].grad.detach().clone().contiguous()

@@ -125,7 +125,9 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(NotImplementedError, match="head_dim"):
         CM3PModel(CM3PConfig(**CASES["c1_tiny_nopad"]["cfg"]))  # head_dim 16: CPU-only config (BASELINE configs[0])
     with pytest.raises(NotImplementedError):
-        CM3PModel(CM3PConfig(has_decoder_head=True))
+        CM3PModel(CM3PConfig(has_decoder_head=True))  # loss_type None: the reference would silently use a causal-LM loss
+    m = CM3PModel(CM3PConfig(**CASES["d64_mlm"]["cfg"]))
+    assert {"head.dense.weight", "head.norm.weight", "decoder.weight", "decoder.bias"} <= set(m.state_dict())
 
 
 def test_later_rows_are_importable_but_not_built():

@@ -35,7 +35,9 @@ def _build(name, dtype=torch.float32):
     cfg = CM3PConfig(**CASES[name]["cfg"])
     model = CM3PModel(cfg)
     sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
-    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    sd.update({k[2:]: v for k, v in blob.items() if k.startswith("w.")})  # parameters only this case has (MLM head)
+    model.load_state_dict(sd, strict=True)
     return model.to(DEV).to(dtype).train()
 
 
@@ -59,6 +61,9 @@ def test_forward_backward_matches_reference_fixture(name):
         got = out.beatmap_model_output.last_hidden_state.float().cpu()
         assert torch.isfinite(got).all()  # includes padded rows whose local-attention window is empty
         assert _rel(got[mask], blob["beatmap_last_hidden_state"][mask]) <= 2e-2
+    if "logits" in blob:  # MLM head: (B, S, vocab) logits, compared on the labelled positions and overall
+        assert out.logits.shape == blob["logits"].shape
+        assert _rel(out.logits, blob["logits"]) <= 3e-2
     if "audio_embeds" in blob:
         got_audio = out.beatmap_model_output.audio_model_output.audio_embeds
         assert got_audio.shape == blob["audio_embeds"].shape

@@ -19,6 +19,7 @@ def _load(name):
     arch = "c1" if name.startswith("c1") else "d64"
     sd = load_file(os.path.join(GOLD, f"weights_{arch}.safetensors"))
     blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    sd.update({k[2:]: v for k, v in blob.items() if k.startswith("w.")})  # parameters only this case has (MLM head)
     return sd, blob
 
 
@@ -49,7 +50,7 @@ def test_forward_matches_reference(name, eager):
     tol = 1e-5 if not eager else 2e-5
     for key in ("loss", "logits_per_metadata", "metadata_embeds", "beatmap_embeds",
                 "beatmap_pooler_output", "metadata_pooler_output",
-                "beatmap_last_hidden_state", "metadata_last_hidden_state", "audio_embeds"):
+                "beatmap_last_hidden_state", "metadata_last_hidden_state", "audio_embeds", "logits"):
         if key in blob:
             _close(out[key].reshape(blob[key].shape), blob[key], tol, f"{name}:{key}")
     if "beatmap_hidden_emb" in blob:
