@@ -387,9 +387,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const bool wave_live = q0 < S;
     const int t_lo = klo / 64, t_hi = khi / 64;
 
-    f32x16 dq[2];
+    f32x16 dq[2], lse_init, dlt_init;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        dq[0][i] = dq[1][i] = 0.f;
+        lse_init[i] = -lse2;
+        dlt_init[i] = -dlt;
+    }
 
     TileRegs64 kr, vr;
     uint8_t mreg = 0;
@@ -426,13 +430,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
             f32x16 sacc[2], dp[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
+                // row constants as initial accumulators (log2 p, and dP - delta): the first MFMA of each chain reads them
+                // from two vectors that stay resident for the whole key sweep (the MFMA's C and D may differ), so no
+                // per-tile register fills are needed
+                sacc[blk] = mfma32(frag_R(st, 32 * blk, 0, lane), qf[0], lse_init);
+                dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, 0, lane), dof[0], dlt_init);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    sacc[blk][i] = -lse2;  // row constants as initial accumulators: log2 p, and dP - delta
-                    dp[blk][i] = -dlt;
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 1; s < 4; ++s) {
                     sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
                     dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp[blk]);
                 }
