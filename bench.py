@@ -123,6 +123,38 @@ def cpu_baseline(workload: str) -> dict:
     }
 
 
+def optimizer_leg(model, steps: int = 3):
+    """The Muon step that follows the hot path, timed OUTSIDE the judged region and reported next to
+    it (§8d: "optimizer excluded from the roofline figure, reported separately").  Parameter split as ref:train.py:331-340,
+    hyper-parameters of the v7 recipe; uses the gradients the last timed step left behind."""
+    from cm3p_amd import _lib
+    from cm3p_amd.muon import Muon
+
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    adamw = [p for n, p in named if any(k in n.lower() for k in ("embed", "proj_out")) or p.ndim <= 1]
+    ids = {id(p) for p in adamw}
+    muon = [p for _, p in named if id(p) not in ids]
+    opt = Muon(muon_params=muon, lr=4e-4, adamw_params=adamw, adamw_lr=1e-4, adamw_betas=(0.9, 0.999), adamw_wd=0.0)
+    opt.step()  # allocates state and workspaces
+    torch.cuda.synchronize()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    prof = _lib.profile_end()
+    n_gemm, gemm_ms, gemm_flop = prof.get("muon_ns_gemm", (0, 0.0, 0.0))
+    return {
+        "kind": "muon (Newton-Schulz x6, batched over same-shaped weights) + multi-tensor AdamW rule",
+        "ms": ms, "muon_matrices": len(muon), "adamw_tensors": len(adamw),
+        "ns_gemm_tflop": gemm_flop / steps / 1e12, "ns_gemm_ms": gemm_ms / steps,
+        "ns_gemm_tflops_achieved": gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
+        "kernels_ms": {k: round(v[1] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+        "launches_per_step": sum(v[0] for v in prof.values()) // steps,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +164,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch (rehearsals only; the judged run uses the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing in the timed region")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported Muon optimizer-step timing")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -229,6 +262,10 @@ def main():
         "step_tflops_algorithmic": flops / 1e12,
         "step_mfma_frac": flops / (ms_per_step * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
     }
+    if not args.no_optimizer:
+        opt_info = optimizer_leg(model)  # every rank steps (replicas must stay identical); rank 0 reports
+        if rank == 0:
+            result["optimizer_step"] = opt_info
     if rank == 0:
         if prof:
             total_ms = sum(v[1] for v in prof.values())

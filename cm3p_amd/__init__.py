@@ -18,4 +18,8 @@ def __getattr__(name):
         from . import modeling_cm3p as m
 
         return getattr(m, name)
+    if name == "Muon":
+        from .muon import Muon
+
+        return Muon
     raise AttributeError(name)

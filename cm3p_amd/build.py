@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "attention.hip", "head.hip", "conv.hip"]
+SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "attention.hip", "head.hip", "conv.hip", "muon.hip"]
 LIB = os.path.join(CSRC, "libcm3p_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

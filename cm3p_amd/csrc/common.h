@@ -13,7 +13,15 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CM3P_WAVE 64
-#define CM3P_EPI_BF16_ROPE 3  // internal: bf16 output with rotary embedding applied to the leading columns
+#define CM3P_EPI_BF16_ROPE 3   // internal: bf16 output with rotary embedding applied to the leading columns
+#define CM3P_EPI_BF16_AXPBY 4  // internal: bf16 output = alpha * acc + beta * Rb (cm3p_gemm_bf16_batched)
+
+// Strided-batch offsets (elements) and the AXPBY epilogue operands of the 128 x 128 GEMM kernel.
+struct BatchArgs {
+    int64_t a_stride = 0, b_stride = 0, c_stride = 0, r_stride = 0;
+    const uint16_t* Rb = nullptr;
+    float alpha = 1.f, beta = 0.f;
+};
 
 // Every extern "C" entry point ends with this: kernels never throw, launch errors become a return code.
 #define CM3P_LAUNCH_CHECK()                                         \

@@ -91,13 +91,16 @@ __device__ __forceinline__ bf16x8 load_frag(const char* stage, int idx0, int kk,
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* A, const uint16_t* B,
                                                            void* __restrict__ Cv, const float* R, int64_t M, int64_t N,
                                                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int tiles_n,
-                                                           int64_t kchunk, int64_t c_split_stride, RopeArgs rope) {
+                                                           int64_t kchunk, int64_t c_split_stride, RopeArgs rope, BatchArgs bt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
+    // blockIdx.y = matrix of a strided batch (1 for the encoder's linears; the Muon step batches same-shaped weights)
+    A += (int64_t)blockIdx.y * bt.a_stride;
+    B += (int64_t)blockIdx.y * bt.b_stride;
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous run of
     // tiles; consecutive tiles share the activation row-panel (tn fastest) and hit that XCD's L2.  Speed only.
@@ -183,6 +186,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
             if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
                 uint16_t* C = static_cast<uint16_t*>(Cv);
                 *reinterpret_cast<uint2*>(C + m * ldc + n) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            } else if constexpr (EPI == CM3P_EPI_BF16_AXPBY) {
+                // C = bf16(alpha * acc + beta * Rb), Rb bf16 with C's layout (the Newton-Schulz polynomial steps)
+                uint16_t* C = static_cast<uint16_t*>(Cv) + (int64_t)blockIdx.y * bt.c_stride;
+                v *= bt.alpha;
+                if (bt.Rb) {
+                    const uint2 r = *reinterpret_cast<const uint2*>(bt.Rb + (int64_t)blockIdx.y * bt.r_stride + m * ldc + n);
+                    v += bt.beta * f32x4{bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y)};
+                }
+                *reinterpret_cast<uint2*>(C + m * ldc + n) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             } else {
                 float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
                 if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
@@ -204,28 +216,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <bool A_KC, bool B_KC>
 int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-           int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope = RopeArgs{}) {
+           int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope = RopeArgs{},
+           BatchArgs bt = BatchArgs{}, int batch = 1) {
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-    const dim3 grid(tiles_m * tiles_n, 1, splits);
+    const dim3 grid(tiles_m * tiles_n, batch, splits);
     const size_t lds = 4 * kStageBytes;
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(B);
     switch (epi) {
         case CM3P_EPI_BF16:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_BF16><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_BF16><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
             break;
         case CM3P_EPI_F32:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
             break;
         case CM3P_EPI_F32_RESID:
-            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32_RESID><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_F32_RESID><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
             break;
         case CM3P_EPI_BF16_ROPE:
             if constexpr (A_KC && B_KC) {
-                gemm_bf16_kernel<true, true, CM3P_EPI_BF16_ROPE><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope);
+                gemm_bf16_kernel<true, true, CM3P_EPI_BF16_ROPE><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
                 break;
             }
             return CM3P_ERR_INVALID;
+        case CM3P_EPI_BF16_AXPBY:
+            gemm_bf16_kernel<A_KC, B_KC, CM3P_EPI_BF16_AXPBY><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
+            break;
         default:
             return CM3P_ERR_INVALID;
     }
@@ -315,6 +331,27 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
         splitk_reduce_kernel<<<(int)blocks, 256, 0, s>>>(workspace, static_cast<float*>(C), n4, split_k, n4);
         CM3P_LAUNCH_CHECK();
     }
+    return CM3P_OK;
+}
+
+int cm3p_gemm_bf16_batched(const void* A, const void* B, void* C, const void* R, int batch, int64_t M, int64_t N, int64_t K,
+                           int64_t lda, int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                           int64_t stride_r, int a_kc, int b_kc, float alpha, float beta, void* stream) {
+    CM3P_REQUIRE(A && B && C && batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0);
+    CM3P_REQUIRE(cm3p_aligned16(A) && cm3p_aligned16(B) && cm3p_aligned16(C) && (!R || cm3p_aligned16(R)));
+    CM3P_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && ldc >= N);
+    CM3P_REQUIRE(stride_a % 8 == 0 && stride_b % 8 == 0 && stride_c % 8 == 0 && stride_r % 8 == 0);
+    CM3P_REQUIRE(a_kc ? (K % 8 == 0 && lda >= K) : (M % 8 == 0 && lda >= M));
+    CM3P_REQUIRE(b_kc ? (K % 8 == 0 && ldb >= K) : (N % 8 == 0 && ldb >= N));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const BatchArgs bt{stride_a, stride_b, stride_c, stride_r, static_cast<const uint16_t*>(R), alpha, beta};
+    int rc;
+    if (a_kc && b_kc) rc = launch<true, true>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
+    else if (a_kc) rc = launch<true, false>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
+    else if (b_kc) rc = launch<false, true>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
+    else rc = launch<false, false>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
+    if (rc != CM3P_OK) return rc;
+    CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
 

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 2
+#define CM3P_ABI_VERSION 3
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -225,6 +225,36 @@ int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, in
 
 /* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
 int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);
+
+/* ---- Muon optimizer step (ref:utils/muon_utils.py:35-57 zeropower_via_newtonschulz5, :138-203 Muon.step) -----------
+ * The step that follows the hot path in every training recipe >= v2 (ref:configs/train/v2.yaml:9).
+ *
+ * cm3p_gemm_bf16_batched: C_b = bf16(alpha * A_b B_b^T + beta * R_b) for b < batch, operands as in cm3p_gemm_bf16, matrix b
+ *   at base + b * stride (elements).  R (bf16, C's layout) may be NULL.  One Newton-Schulz iteration over a group of
+ *   same-shaped weights is three calls: A = X X^T;  B = b A + c A A;  X' = a X + B X  (:50-53).
+ * Same-shaped weights form a group.  Parameters, gradients and optimizer state stay in torch's own allocations and are
+ * passed as DEVICE tables of int64 addresses (fp32, contiguous); the iterate X is a bf16 workspace [n_mat][x_stride]
+ * holding each rows x cols matrix at row pitch ldx (extents rounded up to 8, padding zero).
+ * cm3p_muon_momentum: buf = momentum*buf + g; u = nesterov ? g + momentum*buf : g (as :163-164 does); X = bf16(u);
+ *   partials[mat, 0..cm3p_muon_partials(rows, cols)) = fixed-order partial sums of X^2 (:160-164, :46).
+ *   aligned16 != 0 promises that every address in both tables is 16-byte aligned (enables 16-byte accesses).
+ * cm3p_muon_normalize: X /= bf16(bf16(||X||) + eps), in the reference's bf16 arithmetic (:47).
+ * cm3p_muon_apply: p += neg_lr * float(bf16(X * shape_scale)), shape_scale = sqrt(max(1, rows/cols)) (:173-176).
+ * cm3p_adamw_multi: the reference's AdamW branch for all other parameters in one launch (:178-203):
+ *   m1 = lerp(m1, g, w1); m2 = lerp(m2, g*g, w2); p = p*decay + step_alpha * m1 / (eps + sqrt(m2)).
+ *   The host passes w1 = 1-beta1, w2 = 1-beta2, decay = 1 - adamw_lr*wd, step_alpha = -lr/scale exactly as :195-203 does. */
+int cm3p_gemm_bf16_batched(const void* A, const void* B, void* C, const void* R, int batch, int64_t M, int64_t N, int64_t K,
+                           int64_t lda, int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                           int64_t stride_r, int a_kc, int b_kc, float alpha, float beta, void* stream);
+int cm3p_muon_partials(int rows, int cols);
+int cm3p_muon_momentum(const int64_t* g_ptrs, const int64_t* buf_ptrs, void* X, float* partials, int n_mat, int rows, int cols,
+                       int ldx, int64_t x_stride, float momentum, int nesterov, int aligned16, void* stream);
+int cm3p_muon_normalize(void* X, const float* partials, int n_mat, int rows, int cols, int64_t x_stride, float eps, void* stream);
+int cm3p_muon_apply(const int64_t* p_ptrs, const void* X, int n_mat, int rows, int cols, int ldx, int64_t x_stride,
+                    float shape_scale, float neg_lr, void* stream);
+int cm3p_adamw_multi(const int64_t* p_ptrs, const int64_t* g_ptrs, const int64_t* m1_ptrs, const int64_t* m2_ptrs,
+                     const int64_t* numels, int n_tensors, int64_t max_numel, float w1, float w2, float eps, float decay,
+                     float step_alpha, void* stream);
 
 #ifdef __cplusplus
 }
