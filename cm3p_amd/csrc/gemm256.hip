@@ -24,9 +24,14 @@ __device__ __forceinline__ int kc_off(int r, int c) { return r * 128 + ((c ^ (r 
 __device__ __forceinline__ int ksf(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 __device__ __forceinline__ int ks_off(int k, int idx) { return k * 512 + (((idx >> 4) ^ ksf(k)) << 5) + ((idx & 15) << 1); }
 
+// LDS-DMA of 64 x 16 bytes (lane l's 16 bytes land at lds_wave_base + 16 * l), issued as inline assembly on purpose.
+// Through __builtin_amdgcn_global_load_lds the compiler knows the instruction writes LDS; unable to prove that the fragment
+// reads of the CURRENT stage touch the other half of the buffer, it puts s_waitcnt vmcnt(0) in front of them - i.e. it
+// drains the NEXT stage's loads right after they were issued, and the double buffer overlaps nothing (rocprof: the k-loop
+// sat at 57 % MFMA-busy).  Ordering is explicit instead: the counted/zero vmcnt wait and the barrier that end a k-step.
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
 }
 
 // Per-thread source pointers for the 4 one-KiB pieces this wave stages per operand per k-tile.
