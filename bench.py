@@ -64,7 +64,18 @@ def step_flops(config, w) -> float:
 def make_batch(config, w, rank: int, device):
     from cm3p_amd.synthetic import synthetic_batch
 
-    return {k: v.to(device) for k, v in synthetic_batch(config, w["B"], w["S"], w["L"], seed=1234 + rank, audio_T=w["audio_T"]).items()}
+    batch = {k: v.to(device) for k, v in synthetic_batch(config, w["B"], w["S"], w["L"], seed=1234 + rank, audio_T=w["audio_T"]).items()}
+    if w.get("padded"):
+        # SURVEY.md section 8(d) "padded variant": per-row valid length ~ U{S/2 .. S}, right-padded with pad id 0
+        g = torch.Generator().manual_seed(4321 + rank)
+        S = w["S"]
+        lens = torch.randint(S // 2, S + 1, (w["B"],), generator=g)
+        lens[0] = S
+        valid = (torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)).to(device)
+        batch["attention_mask"] = valid.to(batch["attention_mask"].dtype)
+        batch["input_ids"] = batch["input_ids"] * valid.to(batch["input_ids"].dtype)
+        w["valid_token_fraction"] = float(lens.sum()) / (w["B"] * S)
+    return batch
 
 
 def pmc_traffic(workload: str, tag: str):
@@ -165,6 +176,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing in the timed region")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported Muon optimizer-step timing")
+    ap.add_argument("--padded", action="store_true", help="not the judged configuration: right-padded rows, valid length ~ U{S/2..S}")
+    ap.add_argument("--unpad", action="store_true", help="with --padded: run the beatmap tower on the valid tokens only (unpadded execution)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -192,6 +205,9 @@ def main():
     from cm3p_amd import CM3PConfig, CM3PModel, _lib
 
     w = dict(WORKLOADS[args.workload])
+    if args.padded:
+        w["padded"] = True
+        w["desc"] += " [padded variant: valid length ~ U{S/2..S}" + (", unpadded execution]" if args.unpad else ", padded execution]")
     if args.batch:
         w["B"] = args.batch
         w["desc"] += f" [batch overridden to {args.batch}/GPU]"
@@ -207,6 +223,8 @@ def main():
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                                bucket_cap_mb=128)
     batch = make_batch(config, w, rank, device)
+    if args.unpad:
+        model.unpad_inputs = True
 
     def step():
         for p in model.parameters():
@@ -258,7 +276,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['desc']}", "global_batch": world * w["B"], "beatmap_seq": w["S"],
                    "metadata_seq": w["L"], "parallelism": f"dp{world}" + ("+allgather-negatives" if world > 1 else ""),
-                   "weights": "random init (reference init rules), fp32 master / bf16 GEMM operands", "loss": float(loss.item())},
+                   "weights": "random init (reference init rules), fp32 master / bf16 GEMM operands", "loss": float(loss.item()),
+                   **({"valid_token_fraction": w["valid_token_fraction"]} if "valid_token_fraction" in w else {})},
         "step_tflops_algorithmic": flops / 1e12,
         "step_mfma_frac": flops / (ms_per_step * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
     }

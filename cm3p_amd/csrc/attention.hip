@@ -54,6 +54,34 @@ __device__ __forceinline__ void decode_block(int nblk, int nh, int& blk, int& he
     b = bh / nh;
 }
 
+// Unpadded ("varlen") batches: sequences are packed back to back, sequence b occupies rows cu[b] .. cu[b+1]-1 of the
+// [total, ...] tensors (the layout the reference's flash_attention_2 path builds with _unpad_cm3p_input,
+// ref:cm3p/modeling_cm3p.py:65-134) and the per-row statistics are [nh, total].  cu == nullptr: padded [B, S, ...] tensors.
+struct VarLen {
+    const int* cu;
+    int64_t total;
+};
+struct SeqView {
+    int64_t row0;   // first row of this sequence in the token-major tensors
+    int64_t stat0;  // index of its row 0 in lse / delta for this head
+    int S;          // its length
+    bool packed;
+    __device__ __forceinline__ SeqView(const VarLen& vl, int b, int head, int Smax, int nh) {
+        packed = vl.cu != nullptr;
+        if (packed) {
+            row0 = vl.cu[b];
+            S = vl.cu[b + 1] - vl.cu[b];
+            stat0 = (int64_t)head * vl.total + row0;
+        } else {
+            row0 = (int64_t)b * Smax;
+            S = Smax;
+            stat0 = ((int64_t)b * nh + head) * Smax;
+        }
+    }
+    // first row of the rotary tables for this sequence: packed tables are per token; padded ones per batch row or shared
+    __device__ __forceinline__ int64_t pos0(int b, int64_t pos_batch_stride) const { return packed ? row0 : (int64_t)b * pos_batch_stride; }
+};
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -156,16 +184,19 @@ constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask 
 template <int QSUB>
 __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                                         float* __restrict__ lse, const uint8_t* __restrict__ kmask,
-                                                                        int S, int nh, int window, float scale) {
+                                                                        int Smax, int nh, int window, float scale, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QW = 32 * QSUB;  // queries per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     int qblk, head, b;
-    decode_block((S + 4 * QW - 1) / (4 * QW), nh, qblk, head, b);
+    decode_block((Smax + 4 * QW - 1) / (4 * QW), nh, qblk, head, b);
     const int Q0 = qblk * (4 * QW);
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (Q0 >= S) return;  // (unpadded batches: the grid is sized for the longest sequence)
     const int q0 = Q0 + wid * QW;
     const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
     const float c = scale * kLog2e;
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
         gload64(vr, vbase, ld, t * 64, S, tid);
         if (tid < 64) {
             const int key = t * 64 + tid;
-            mreg = key < S ? (kmask ? kmask[(int64_t)b * S + key] : (uint8_t)1) : (uint8_t)0;
+            mreg = key < S ? (kmask ? kmask[sv.row0 + key] : (uint8_t)1) : (uint8_t)0;
         }
     };
     auto lstore = [&](int stage) {
@@ -313,7 +344,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
         const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         if (qrow[u] < S) {
-            uint16_t* orow = out + ((int64_t)b * S + qrow[u]) * nh * 64 + head * 64;
+            uint16_t* orow = out + (sv.row0 + qrow[u]) * nh * 64 + head * 64;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
                     *reinterpret_cast<uint2*>(orow + dv) = w;
                 }
             if (hh == 0)
-                lse[((int64_t)b * nh + head) * S + qrow[u]] =
+                lse[sv.stat0 + qrow[u]] =
                     l_tot > 0.f ? (mc_run[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
         }
     }
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 // delta[b, h, q] = sum_d dO[q, d] * O[q, d]
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int64_t T, int S, int nh) {
+                                                         float* __restrict__ delta, int64_t T, int S, int nh, int packed) {
     const int64_t total = T * nh * 8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total + 7; i += (int64_t)gridDim.x * 256) {
         const bool ok = i < total;
@@ -353,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
         if (ok && c == 0) {
             const int64_t tok = row / nh;
             const int h = (int)(row % nh);
-            delta[((tok / S) * nh + h) * S + tok % S] = s;
+            delta[packed ? (int64_t)h * T + tok : ((tok / S) * nh + h) * S + tok % S] = s;
         }
     }
 }
@@ -366,21 +397,24 @@ constexpr int kDqStage = 2 * 8192 + 64 + 16;  // K image, V image, mask bytes, a
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                             int S, int nh, int window, float scale,
+                                                             int Smax, int nh, int window, float scale,
                                                              const float* __restrict__ rope_cos,
-                                                             const float* __restrict__ rope_sin, int64_t pos_batch_stride) {
+                                                             const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     int qblk, head, b;
-    decode_block((S + 127) / 128, nh, qblk, head, b);
+    decode_block((Smax + 127) / 128, nh, qblk, head, b);
     const int Q0 = qblk * 128;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (Q0 >= S) return;
     const int q0 = Q0 + wid * 32;
     const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
     const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* dobase = d_o + (int64_t)b * S * ldo + head * 64;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
 
     const int qrow = q0 + (lane & 31);
     const int qrow_c = qrow < S ? qrow : S - 1;
@@ -392,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh), c);
         dof[s] = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
     }
-    const int64_t stat = ((int64_t)b * nh + head) * S + qrow_c;
+    const int64_t stat = sv.stat0 + qrow_c;
     const float lse2 = lse[stat] * kLog2e;  // +inf for rows with no visible key -> p = 0
     const float dlt = delta[stat];
 
@@ -422,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         gload64(vr, vbase, ld, t * 64, S, tid);
         if (tid < 64) {
             const int key = t * 64 + tid;
-            mreg = key < S ? (kmask ? kmask[(int64_t)b * S + key] : (uint8_t)1) : (uint8_t)0;
+            mreg = key < S ? (kmask ? kmask[sv.row0 + key] : (uint8_t)1) : (uint8_t)0;
         }
     };
     auto lstore = [&](int stage) {
@@ -485,9 +519,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     }
 
     if (qrow < S) {
-        uint16_t* drow = dqkv + ((int64_t)b * S + qrow) * ld + head * 64;
+        uint16_t* drow = dqkv + (sv.row0 + qrow) * ld + head * 64;
         if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
-            const int64_t prow = (int64_t)b * pos_batch_stride + qrow;
+            const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 lo4 = {dq[0][4 * g], dq[0][4 * g + 1], dq[0][4 * g + 2], dq[0][4 * g + 3]};
@@ -522,23 +556,26 @@ constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, -lse*log2e and 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                              int S, int nh, int window, float scale,
+                                                              int Smax, int nh, int window, float scale,
                                                               const float* __restrict__ rope_cos,
-                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride) {
+                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     int kblk, head, b;
-    decode_block((S + 127) / 128, nh, kblk, head, b);
+    decode_block((Smax + 127) / 128, nh, kblk, head, b);
     const int K0 = kblk * 128;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (K0 >= S) return;
     const int k0 = K0 + wid * 32;
     const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + (int64_t)b * S * ld + head * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
     const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* dobase = d_o + (int64_t)b * S * ldo + head * 64;
-    const float* lse_bh = lse + ((int64_t)b * nh + head) * S;
-    const float* dlt_bh = delta + ((int64_t)b * nh + head) * S;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
+    const float* lse_bh = lse + sv.stat0;
+    const float* dlt_bh = delta + sv.stat0;
 
     const int krow = k0 + (lane & 31);
     const int krow_c = krow < S ? krow : S - 1;
@@ -549,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         kf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh), c);
         vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
     }
-    const bool key_ok = krow < S && (kmask ? kmask[(int64_t)b * S + krow] != 0 : true);
+    const bool key_ok = krow < S && (kmask ? kmask[sv.row0 + krow] != 0 : true);
     const bool keys_all_ok = __all(key_ok);
     const int lo = window < 0 ? INT_MIN : krow - window, hi = window < 0 ? INT_MAX : krow + window;
 
@@ -658,10 +695,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }
 
     if (krow < S) {
-        uint16_t* dkrow = dqkv + ((int64_t)b * S + krow) * ld + nh * 64 + head * 64;
+        uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
         uint16_t* dvrow = dkrow + nh * 64;
         if (rope_cos) {
-            const int64_t prow = (int64_t)b * pos_batch_stride + krow;
+            const int64_t prow = sv.pos0(b, pos_batch_stride) + krow;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 lo4 = {dk[0][4 * g], dk[0][4 * g + 1], dk[0][4 * g + 2], dk[0][4 * g + 3]};
@@ -690,17 +727,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 }  // namespace
 
+static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
+                           float scale, VarLen vl, hipStream_t s) {
+    // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
+    // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
+    const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
+    attn_fwd_kernel<1><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
+    return CM3P_OK;
+}
+
+static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                           const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
+                           const float* sin_tab, int64_t pos_batch_stride, VarLen vl, hipStream_t s) {
+    const int64_t T = vl.cu ? vl.total : (int64_t)B * S;
+    int64_t blocks = (T * nh * 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    attn_delta_kernel<<<(int)blocks, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, T, S, nh, vl.cu ? 1 : 0);
+    if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+    const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
+    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                       key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+    if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+    attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                         key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+    return CM3P_OK;
+}
+
 extern "C" {
 
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                   float scale, void* stream) {
     CM3P_REQUIRE(qkv && out && lse && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
-    // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
-    const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    attn_fwd_kernel<1><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale);
+    const int rc = launch_attn_fwd(qkv, out, lse, key_mask, B, S, nh, window, scale, VarLen{nullptr, 0}, static_cast<hipStream_t>(stream));
+    if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -712,18 +772,33 @@ int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
     CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t T = (int64_t)B * S;
-    int64_t blocks = (T * nh * 8 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    attn_delta_kernel<<<(int)blocks, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, T, S, nh);
+    const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, window, scale, cos_tab, sin_tab,
+                                   pos_batch_stride, VarLen{nullptr, 0}, static_cast<hipStream_t>(stream));
+    if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
-    const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                       key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride);
+    return CM3P_OK;
+}
+
+int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_seqlens, int B, int max_seqlen, int64_t total,
+                         int nh, int window, float scale, void* stream) {
+    CM3P_REQUIRE(qkv && out && lse && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
+    CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
+    const int rc = launch_attn_fwd(qkv, out, lse, nullptr, B, max_seqlen, nh, window, scale, VarLen{cu_seqlens, total},
+                                   static_cast<hipStream_t>(stream));
+    if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
-    attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                         key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride);
+    return CM3P_OK;
+}
+
+int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                         const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
+                         const float* cos_tab, const float* sin_tab, void* stream) {
+    CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
+    CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
+    CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
+    const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, nullptr, B, max_seqlen, nh, window, scale, cos_tab, sin_tab, 0,
+                                   VarLen{cu_seqlens, total}, static_cast<hipStream_t>(stream));
+    if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

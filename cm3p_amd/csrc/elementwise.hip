@@ -231,6 +231,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
 }
 
+// dst row i = src row idx[i] (GATHER) or dst row idx[i] = src row i (scatter); rows of H fp32 values, H % 4 == 0
+template <bool GATHER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                        float* __restrict__ dst, int64_t n, int h4) {
+    const int64_t total = n * h4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / h4;
+        const int c = (int)(i - r * h4);
+        const int64_t other = idx[r];
+        if constexpr (GATHER) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[other * h4 + c];
+        else reinterpret_cast<f32x4*>(dst)[other * h4 + c] = reinterpret_cast<const f32x4*>(src)[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -251,6 +265,22 @@ int cm3p_add_f32(const float* a, const void* b, int b_dtype, float* y_f32, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (b_dtype == CM3P_BF16) add_f32_kernel<true><<<ew_grid(n / 4), 256, 0, s>>>(a, b, y_f32, (uint16_t*)y_bf16, n / 4);
     else add_f32_kernel<false><<<ew_grid(n / 4), 256, 0, s>>>(a, b, y_f32, (uint16_t*)y_bf16, n / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_gather_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream) {
+    CM3P_REQUIRE(src && idx && dst && n >= 0 && H > 0 && H % 4 == 0 && cm3p_aligned16(src) && cm3p_aligned16(dst));
+    if (n == 0) return CM3P_OK;
+    move_rows_kernel<true><<<ew_grid(n * (H / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, idx, dst, n, H / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_scatter_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream) {
+    CM3P_REQUIRE(src && idx && dst && n >= 0 && H > 0 && H % 4 == 0 && cm3p_aligned16(src) && cm3p_aligned16(dst));
+    if (n == 0) return CM3P_OK;
+    move_rows_kernel<false><<<ew_grid(n * (H / 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(src, idx, dst, n, H / 4);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -193,11 +193,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
             // rotate in registers, in fp32, before rounding: the wave's 64 columns are one head, dims d and d+32 are
             // accumulator tiles j and j+2 of the same lane
             if (n0 + wn * 64 < rope.ncols) {
+                // table row of token m is m (per-batch positions) or m mod S: one modulo per lane and tile, then the row groups
+                // (16 rows apart) advance it with a conditional subtract - eight 64-bit modulos per tile cost ~50 VGPRs of
+                // temporaries (spills) and a few hundred instructions
+                const int64_t mrow0 = m0 + wm * 128 + (lane & 15);
+                const int p0 = rope.per_batch ? 0 : (int)(mrow0 % rope.S);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    int64_t m = m0 + wm * 128 + i * 16 + (lane & 15);
-                    if (m > M - 1) m = M - 1;
-                    const int64_t prow = rope.per_batch ? m : m % rope.S;
+                    int64_t m = mrow0 + i * 16;
+                    if (m > M - 1) m = M - 1;  // rows past the edge are never stored; any valid table row will do
+                    int pw = p0 + i * 16;
+                    if (rope.S >= 128) pw = pw >= rope.S ? pw - rope.S : pw;
+                    else pw %= rope.S;
+                    const int64_t prow = rope.per_batch ? m : (int64_t)pw;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));

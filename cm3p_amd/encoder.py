@@ -90,7 +90,7 @@ def _bf16_weight(w: Tensor) -> Tensor:
 class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
-    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save")
+    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s")
 
 
 class _EncoderStackFn(torch.autograd.Function):
@@ -114,7 +114,10 @@ class _EncoderStackFn(torch.autograd.Function):
             else:
                 _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, geo.save)
             qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
-            o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
+            if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
+                o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
+            else:
+                o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
             x_mid = K.linear_fwd(o, Wo_b, resid=x)
             _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, geo.save)
             h = K.linear_fwd(xn2, Wi_b)
@@ -164,7 +167,10 @@ class _EncoderStackFn(torch.autograd.Function):
             do = K.linear_dgrad(gx16, Wo_b)
             dWo = K.linear_wgrad(gx16, o)
             # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
-            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
+            if geo.cu is not None:
+                dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i])
+            else:
+                dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
             del do, o, qkv
             dxn = K.linear_dgrad(dqkv, Wqkv_b)
             dWqkv = K.linear_wgrad(dqkv, xn)
@@ -210,6 +216,23 @@ class _EmbedLNFn(torch.autograd.Function):
         if d_audio is not None and d_audio.dtype != ad:
             d_audio = d_audio.to(ad)
         return None, d_table, dw.to(wd), None, None, None, d_audio
+
+
+class _PadRowsFn(torch.autograd.Function):
+    """Packed rows -> padded [rows, H] with zeros at the padding positions (ref:cm3p/modeling_cm3p.py:106-134 _pad_cm3p_output);
+    backward gathers the rows back."""
+
+    @staticmethod
+    def forward(ctx, y: Tensor, idx: Tensor, n_valid: int, rows: int):
+        ctx.idx, ctx.n_valid, ctx.packed_rows = idx, n_valid, y.shape[0]
+        return K.scatter_rows(y[:n_valid].contiguous() if n_valid != y.shape[0] else y.contiguous(), idx, rows)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        g = K.gather_rows(dy.contiguous(), ctx.idx)
+        if ctx.packed_rows != ctx.n_valid:  # alignment rows of the packed layout take no gradient
+            g = torch.cat((g, torch.zeros((ctx.packed_rows - ctx.n_valid, g.shape[1]), dtype=g.dtype, device=g.device)))
+        return g, None, None, None
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -280,8 +303,12 @@ class CM3PEncoder(nn.Module):
 
     def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 position_ids: Optional[Tensor] = None, inputs_embeds: Optional[Tensor] = None,
-                audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None) -> Tensor:
-        """-> last_hidden_state (B, S, H) fp32.  Exactly one of input_ids / inputs_embeds."""
+                audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None, unpad: bool = False) -> Tensor:
+        """-> last_hidden_state (B, S, H) fp32.  Exactly one of input_ids / inputs_embeds.
+
+        unpad: run the stack on the valid tokens only, packed back to back (what the reference's flash_attention_2 path does,
+        ref:cm3p/modeling_cm3p.py:911-931); padding positions of the result are zero.  Used when the mask is a right-padded
+        one with at least one padded position; otherwise the padded path runs (same values on the valid positions)."""
         cfg = self.config
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
@@ -292,7 +319,19 @@ class CM3PEncoder(nn.Module):
         H = cfg.hidden_size
         dev = ref.device
 
-        if input_ids is not None:
+        packed = None
+        if unpad and attention_mask is not None and input_ids is not None and audio_slot is None:
+            packed = self._plan_unpadded(attention_mask.reshape(B, S), position_ids)
+
+        if packed is not None:
+            idx, cu, max_s, n_valid, n_rows, pos = packed
+            ids = input_ids.contiguous().view(-1)[idx]  # integer row selection (the reference's _unpad_cm3p_input)
+            if n_rows != n_valid:  # alignment rows: one extra pseudo-sequence of pad tokens, no gradient flows into it
+                ids = torch.cat((ids, ids.new_zeros(n_rows - n_valid)))
+            pad = self.embeddings.tok_embeddings.padding_idx
+            x0 = _EmbedLNFn.apply(ids, self.embeddings.tok_embeddings.weight, self.embeddings.norm.weight, cfg.norm_eps,
+                                  -1 if pad is None else pad, None, None)
+        elif input_ids is not None:
             pad = self.embeddings.tok_embeddings.padding_idx
             x0 = _EmbedLNFn.apply(input_ids.contiguous().view(-1), self.embeddings.tok_embeddings.weight,
                                   self.embeddings.norm.weight, cfg.norm_eps, -1 if pad is None else pad, audio_slot, audio_rows)
@@ -304,21 +343,58 @@ class CM3PEncoder(nn.Module):
         geo.eps = cfg.norm_eps
         geo.windows = [-1 if cfg.is_global_layer(i) else cfg.half_window for i in range(geo.L)]
         geo.key_mask = None
-        if attention_mask is not None:
-            # padding term of the reference mask depends on the key only (TF:masking_utils.py:168-179)
-            geo.key_mask = (attention_mask.reshape(B, S) != 0).to(torch.uint8).contiguous()
-        if position_ids is None:
-            position_ids = torch.arange(S, device=dev).unsqueeze(0)
-        geo.per_batch_pos = position_ids.shape[0] != 1
-        if geo.per_batch_pos and position_ids.shape[0] != B:
-            raise ValueError("position_ids must be (1, S) or (B, S)")
-        pos = position_ids.contiguous().to(torch.int64)
+        geo.cu = None
+        geo.max_s = S
+        if packed is not None:
+            geo.B = cu.numel() - 1  # (+1 when alignment rows form a pseudo-sequence)
+            geo.S = max_s
+            geo.cu, geo.max_s = cu, max_s
+            geo.per_batch_pos = True  # rotary tables are per packed token
+            pos_tok = pos
+        else:
+            if attention_mask is not None:
+                # padding term of the reference mask depends on the key only (TF:masking_utils.py:168-179)
+                geo.key_mask = (attention_mask.reshape(B, S) != 0).to(torch.uint8).contiguous()
+            if position_ids is None:
+                position_ids = torch.arange(S, device=dev).unsqueeze(0)
+            geo.per_batch_pos = position_ids.shape[0] != 1
+            if geo.per_batch_pos and position_ids.shape[0] != B:
+                raise ValueError("position_ids must be (1, S) or (B, S)")
+            pos_tok = position_ids.contiguous().to(torch.int64)
         tables = {}
         for is_global, theta in ((True, cfg.global_rope_theta), (False, cfg.local_rope_theta)):
             if any(cfg.is_global_layer(i) == is_global for i in range(geo.L)):
-                tables[is_global] = K.rope_table(pos, self._inv_freq(theta, dev))
+                tables[is_global] = K.rope_table(pos_tok, self._inv_freq(theta, dev))
         geo.rope = [tables[cfg.is_global_layer(i)] for i in range(geo.L)]
         weights = self._stack_weights()
         geo.save = torch.is_grad_enabled() and (x0.requires_grad or any(w.requires_grad for w in weights))
         y = _EncoderStackFn.apply(geo, x0, *weights)
+        if packed is not None:
+            y = _PadRowsFn.apply(y, idx, n_valid, B * S)
         return y.view(B, S, H)
+
+    @staticmethod
+    def _plan_unpadded(mask: Tensor, position_ids: Optional[Tensor]):
+        """Index bookkeeping of _unpad_cm3p_input (ref:cm3p/modeling_cm3p.py:88-104) on the device plus ONE host read (the
+        reference reads max_seqlen the same way).  -> (indices, cu_seqlens, max_seqlen, n_valid, n_rows, positions) or None
+        when unpadding does not apply: nothing padded, an empty row, or a mask that is not right-padded (then the padded path
+        keeps the reference's sdpa semantics exactly)."""
+        B, S = mask.shape
+        m = mask != 0
+        lens = m.sum(dim=1, dtype=torch.int32)
+        last = (m * torch.arange(1, S + 1, device=mask.device)).amax(dim=1).to(torch.int32)  # 1 + index of the last valid key
+        total, max_s, min_s, prefix = torch.stack((lens.sum(), lens.max(), lens.min(), (last == lens).all().to(torch.int32))).tolist()
+        if total == B * S or min_s == 0 or not prefix:
+            return None
+        idx = torch.nonzero(m.flatten()).flatten()
+        n_rows = (total + 63) // 64 * 64  # keeps the token-contraction GEMMs (weight gradients) on the 256 x 256 kernel
+        seq = lens if n_rows == total else torch.cat((lens, lens.new_full((1,), n_rows - total)))
+        cu = torch.zeros(seq.numel() + 1, dtype=torch.int32, device=mask.device)
+        cu[1:] = torch.cumsum(seq, 0)
+        if position_ids is None:
+            pos = idx % S
+        else:
+            pos = position_ids.expand(B, S).reshape(-1)[idx]
+        if n_rows != total:
+            pos = torch.cat((pos, torch.arange(n_rows - total, device=mask.device)))
+        return idx, cu, max(int(max_s), n_rows - total), int(total), int(n_rows), pos.contiguous().to(torch.int64)

@@ -186,6 +186,41 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     return dqkv
 
 
+def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int, scale: float):
+    """Packed sequences: qkv [total, 3, nh, 64], cu int32 [B+1] -> out [total, nh*64], lse [nh, total]."""
+    total = qkv.shape[0]
+    out = torch.empty((total, nh * 64), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((nh, total), dtype=torch.float32, device=qkv.device)
+    call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse), ptr(cu), B, max_s, total, nh, window, scale, stream(),
+         tag="attn_fwd_kernel" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+    return out, lse
+
+
+def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int,
+                    scale: float, rope: Optional[tuple] = None) -> Tensor:
+    """rope = (cos, sin) per packed token [total, 32]: also applies the inverse rotation to dq / dk."""
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    cos, sin = rope if rope is not None else (None, None)
+    call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(cu), B, max_s, qkv.shape[0], nh,
+         window, scale, ptr(cos), ptr(sin), stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+    return dqkv
+
+
+def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
+    """src [R, H] fp32, idx int64 [n] -> [n, H] (the row selection of _unpad_cm3p_input)."""
+    out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    call("cm3p_gather_rows_f32", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], stream())
+    return out
+
+
+def scatter_rows(src: Tensor, idx: Tensor, rows: int) -> Tensor:
+    """src [n, H] fp32 -> [rows, H] with row idx[i] = src[i] and zeros elsewhere (_pad_cm3p_output)."""
+    out = torch.zeros((rows, src.shape[1]), dtype=torch.float32, device=src.device)
+    call("cm3p_scatter_rows_f32", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ MLP pieces
 def geglu_fwd(h: Tensor) -> Tensor:
     T, I2 = h.shape

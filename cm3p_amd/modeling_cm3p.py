@@ -415,6 +415,7 @@ class CM3PBeatmapTransformer(nn.Module):
         self.config = config
         self.audio_encoder = CM3PAudioEncoder(config.audio_config)
         self.encoder = CM3PEncoder(config)
+        self.unpad_inputs = None  # None: follow config._attn_implementation == 'flash_attention_2' (the reference's rule)
 
     def get_input_embeddings(self):
         return self.encoder.get_input_embeddings()
@@ -447,8 +448,12 @@ class CM3PBeatmapTransformer(nn.Module):
                 n = int(count.item())
                 if n != rows.shape[0]:
                     raise RuntimeError(f"shape mismatch: {n} audio placeholder tokens but {rows.shape[0]} audio embeddings")
+            # unpadded execution when asked for explicitly (unpad_inputs) or, like the reference, when the configuration says
+            # flash_attention_2 (ref:cm3p/modeling_cm3p.py:911-931); the encoder falls back to the padded path where it does not apply
+            unpad = self.unpad_inputs if self.unpad_inputs is not None else \
+                getattr(self.config, "_attn_implementation", None) == "flash_attention_2"
             h = self.encoder(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, audio_slot=slot,
-                             audio_rows=rows)
+                             audio_rows=rows, unpad=bool(unpad))
         pooled = _PoolFn.apply(h, attention_mask, bool(self.config.cls_embed)) if output_pooler else None
         return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=None, attentions=None,
                                       audio_model_output=audio_out)
@@ -530,6 +535,7 @@ class CM3PModel(CM3PPreTrainedModel):
             self.decoder = nn.Linear(bc.hidden_size, bc.vocab_size, bias=bc.decoder_bias)
         # Opt-in: in-batch negatives across all ranks of the default process group (new behaviour).
         self.gather_negatives = False
+        self.unpad_inputs = None  # True / False overrides the reference's rule (unpad iff attn_implementation is flash_attention_2)
         self.post_init()
 
     def get_metadata_features(self, input_ids=None, output_attentions=None, output_hidden_states=None) -> Tensor:
@@ -578,6 +584,8 @@ class CM3PModel(CM3PPreTrainedModel):
         loss = 0 if return_loss else None
 
         if input_ids is not None:
+            if self.unpad_inputs is not None or getattr(self.config, "_attn_implementation", None) == "flash_attention_2":
+                self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
             beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
                                                  position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
                                                  cu_seqlens=cu_seqlens, output_attentions=output_attentions,

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 3
+#define CM3P_ABI_VERSION 4
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -225,6 +225,21 @@ int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, in
 
 /* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
 int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);
+
+/* ---- Unpadded ("varlen") execution (ref:cm3p/modeling_cm3p.py:65-134 _unpad_cm3p_input / _pad_cm3p_output, :911-931;
+ * the flash_attn_varlen path of TF:models/modernbert/modeling_modernbert.py).  Valid tokens are packed back to back:
+ * sequence b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 (int32, B+1 entries, device) of qkv [total, 3, nh, 64],
+ * out [total, nh, 64] and of the per-token rotary tables [total, 32]; lse / delta are [nh, total].  No key mask: every packed
+ * token is valid.  Same kernels, same window rule and same results on the valid tokens as cm3p_attn_fwd / cm3p_attn_bwd.
+ * cm3p_gather_rows_f32: dst[i, :] = src[idx[i], :];  cm3p_scatter_rows_f32: dst[idx[i], :] = src[i, :] (dst pre-zeroed by the
+ * caller = _pad_cm3p_output); rows of H fp32 values, H % 4 == 0. */
+int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_seqlens, int B, int max_seqlen, int64_t total,
+                         int nh, int window, float scale, void* stream);
+int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                         const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
+                         const float* cos_tab, const float* sin_tab, void* stream);
+int cm3p_gather_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
+int cm3p_scatter_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
 
 /* ---- Muon optimizer step (ref:utils/muon_utils.py:35-57 zeropower_via_newtonschulz5, :138-203 Muon.step) -----------
  * The step that follows the hot path in every training recipe >= v2 (ref:configs/train/v2.yaml:9).

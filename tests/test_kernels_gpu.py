@@ -453,3 +453,48 @@ def test_audio_conv_frontend_matches_conv1d(K):
     assert rel(got.detach(), y.detach()) <= 1e-2
     for p, r, nm in zip(ps, (w1, b1, w2, b2), ("w1", "b1", "w2", "b2")):
         assert rel(p.grad, r.grad) <= 2e-2, (nm, rel(p.grad, r.grad))
+
+
+# ------------------------------------------------------------------------------------------------- unpadded attention
+@pytest.mark.parametrize("window", [-1, 64])
+def test_attention_varlen_equals_padded_on_valid_rows(K, window):
+    """cm3p_attn_*_varlen on packed sequences == cm3p_attn_* on the right-padded batch, bit for bit, on every valid row
+    (masked keys contribute exact zeros, so packing must not change a single bit), forward and backward with the RoPE epilogue."""
+    torch.manual_seed(0)
+    B, S, nh = 4, 333, 2
+    lens = [333, 200, 97, 64]
+    qkv = (torch.randn(B, S, 3, nh, 64, device=DEV) * 0.7).bfloat16()
+    do = torch.randn(B * S, nh * 64, device=DEV).bfloat16()
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    do = do * mask.reshape(B * S, 1).to(do.dtype)  # padded queries carry no gradient (in the model they never reach the loss)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=DEV, dtype=torch.float32) / 64))
+    cos, sin = K.rope_table(torch.arange(S, device=DEV), inv_freq)
+    out, lse = K.attn_fwd(qkv, mask, B, S, nh, window, 0.125)
+    dqkv = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, window, 0.125, (cos, sin), False)
+
+    idx = torch.nonzero(mask.flatten()).flatten()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    qkv_p = qkv.reshape(B * S, 3, nh, 64)[idx].contiguous()
+    do_p = do[idx].contiguous()
+    pos = (idx % S).contiguous()
+    cos_p, sin_p = K.rope_table(pos, inv_freq)
+    out_p, lse_p = K.attn_fwd_varlen(qkv_p, cu, B, max(lens), nh, window, 0.125)
+    dqkv_p = K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, window, 0.125, (cos_p, sin_p))
+    torch.cuda.synchronize()
+    assert torch.equal(out_p, out[idx])
+    lse_rows = lse.permute(1, 0, 2).reshape(nh, B * S)[:, idx]  # [B, nh, S] -> [nh, total]
+    assert torch.equal(lse_p, lse_rows)
+    assert torch.equal(dqkv_p, dqkv.reshape(B * S, 3, nh, 64)[idx])
+
+
+def test_gather_scatter_rows(K):
+    x = torch.randn(37, 64, device=DEV)
+    idx = torch.tensor([5, 0, 36, 7, 8], device=DEV)
+    g = K.gather_rows(x, idx)
+    assert torch.equal(g, x[idx])
+    sc = K.scatter_rows(g, idx, 37)
+    want = torch.zeros_like(x)
+    want[idx] = x[idx]
+    assert torch.equal(sc, want)

@@ -246,3 +246,64 @@ def test_two_rank_gathered_step_equals_single_process_global_batch():
         assert _rel(out[r][1], model.beatmap_model.encoder.layers[1].attn.Wqkv.weight.grad) <= 2e-2
         assert abs(out[r][2].item() - model.logit_scale.grad.item()) <= 2e-3 * max(1.0, abs(model.logit_scale.grad.item()))
         assert _rel(out[r][3], model.metadata_projection.weight.grad) <= 2e-2
+
+
+# ------------------------------------------------------------------------------------------------- unpadded execution
+@pytest.mark.parametrize("name", ["d64_mean_pad", "d64_mean_longpad", "d64_ragged", "d64_mlm"])
+def test_unpadded_execution_matches_the_reference_fixture(name):
+    """unpad_inputs=True packs the valid tokens (the reference's flash_attention_2 path, ref:cm3p/modeling_cm3p.py:911-931) and must
+    give the reference's results on every VALID position, the same pooled outputs / loss / gradients (same tolerances as the
+    padded path), and zeros at the padding positions of last_hidden_state (= _pad_cm3p_output)."""
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    from cm3p_amd import _lib
+
+    model = _build(name)
+    model.unpad_inputs = True
+    _lib.profile_begin()
+    out = model(**_inputs(blob))
+    tags = set(_lib.profile_end())
+    assert any("varlen" in t for t in tags), tags  # the packed kernels really ran (no silent padded fallback)
+    assert abs(out.loss.item() - blob["loss"].item()) <= 3e-2, (out.loss.item(), blob["loss"].item())
+    assert _rel(out.logits_per_metadata, blob["logits_per_metadata"]) <= 3e-2
+    assert _rel(out.beatmap_embeds, blob["beatmap_embeds"]) <= 2e-2
+    assert _rel(out.beatmap_model_output.pooler_output, blob["beatmap_pooler_output"]) <= 2e-2
+    mask = blob["in.attention_mask"].bool()
+    assert not mask.all(), "fixture must contain padding for this test to mean anything"
+    got = out.beatmap_model_output.last_hidden_state.float().cpu()
+    if "beatmap_last_hidden_state" in blob:
+        assert _rel(got[mask], blob["beatmap_last_hidden_state"][mask]) <= 2e-2
+    assert got[~mask].abs().max().item() == 0.0  # padding rows are zero-filled, as _pad_cm3p_output does
+    if "logits" in blob:
+        assert _rel(out.logits[mask.to(out.logits.device)], blob["logits"][mask]) <= 3e-2
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for k, v in blob.items():
+        if not k.startswith("grad."):
+            continue
+        g = params[k[5:]].grad
+        assert g is not None, k
+        if v.norm() < 1e-8:
+            assert g.float().norm().item() < 1e-5, k
+        else:
+            assert _rel(g, v) <= 6e-2, f"{k}: rel L2 {_rel(g, v):.3e}"
+        checked += 1
+    assert checked >= 10
+
+
+def test_unpadded_and_padded_paths_agree_and_full_batches_stay_padded():
+    """Same kernels on the same valid tokens: packed and padded execution agree to bf16 noise; a batch without padding is not
+    repacked (nothing to gain) and still runs."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    a, b = _build(name), _build(name)
+    b.unpad_inputs = True
+    with torch.no_grad():
+        oa, ob = a(**_inputs(blob)), b(**_inputs(blob))
+    assert _rel(ob.beatmap_embeds, oa.beatmap_embeds) <= 5e-3
+    full = load_file(os.path.join(GOLD, "d64_cls_nopad.safetensors"))
+    c = _build("d64_cls_nopad")
+    c.unpad_inputs = True
+    with torch.no_grad():
+        oc = c(**_inputs(full))
+    assert abs(oc.loss.item() - full["loss"].item()) <= 3e-2
