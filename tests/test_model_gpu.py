@@ -307,3 +307,35 @@ def test_unpadded_and_padded_paths_agree_and_full_batches_stay_padded():
     with torch.no_grad():
         oc = c(**_inputs(full))
     assert abs(oc.loss.item() - full["loss"].item()) <= 3e-2
+
+
+# ------------------------------------------------------------------------------------------------- inference consumers
+def test_extraction_and_variation_eval_paths():
+    """the two forward-only consumers of the same kernels.
+    (1) ref:extract_beatmap_embeddings.py:217-234 calls model(input_ids, attention_mask, return_loss=False) without metadata under
+        no_grad and reads outputs.beatmap_embeds; (2) evaluation scores every beatmap against V metadata variations per row
+        (ref:configs/train/default.yaml:147 test_metadata_variations) - a (B, V, L) metadata batch with variation classes."""
+    name = "d64_variations"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name).eval()
+    inp = _inputs(blob)
+    with torch.no_grad():
+        full = model(**inp)
+        only = model(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], return_loss=False)
+    assert only.loss is None and only.logits_per_metadata is None and only.metadata_embeds is None
+    assert torch.equal(only.beatmap_embeds, full.beatmap_embeds)
+    assert _rel(only.beatmap_embeds, blob["beatmap_embeds"]) <= 2e-2
+
+    # many variations per row: shapes, finiteness, and row 0 of the big batch equals the small batch's scores
+    B, V, L = inp["metadata_ids"].shape
+    reps = 16
+    big_ids = inp["metadata_ids"].repeat(1, reps, 1)
+    big_mask = inp["metadata_attention_mask"].repeat(1, reps, 1)
+    big_cls = inp["metadata_variation_classes"].repeat(1, reps)
+    big_cls[:, V:] = big_cls[:, V:].clamp_min(1) * (big_cls[:, V:] != 0) + (big_cls[:, V:] == 0) * 1  # one original per row only
+    with torch.no_grad():
+        big = model(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], metadata_ids=big_ids,
+                    metadata_attention_mask=big_mask, metadata_variation_classes=big_cls, return_loss=True)
+    assert big.logits_per_metadata.shape == (B, V * reps, B)
+    assert torch.isfinite(big.logits_per_metadata).all() and torch.isfinite(big.loss)
+    assert torch.equal(big.logits_per_metadata[:, :V], full.logits_per_metadata)
