@@ -650,10 +650,107 @@ def _later_row(name: str, row: str):
     return _NotInThisBuild
 
 
-CM3PForMaskedLM = _later_row("CM3PForMaskedLM", "SURVEY.md §8(f) rank 2: MLM head")
+class CM3PMetadataModelWithProjection(CM3PPreTrainedModel):
+    """Metadata tower + projection, un-normalised (ref:cm3p/modeling_cm3p.py:1015-1065)."""
+
+    config_class = CM3PMetadataConfig
+
+    def __init__(self, config: CM3PMetadataConfig):
+        super().__init__(config)
+        self.metadata_model = CM3PMetadataTransformer(config)
+        self.metadata_projection = nn.Linear(config.hidden_size, config.projection_dim, bias=False)
+        self.post_init()
+
+    def get_input_embeddings(self) -> nn.Module:
+        return self.metadata_model.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.metadata_model.set_input_embeddings(value)
+
+    def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None, output_attentions=None,
+                output_hidden_states=None) -> CM3PMetadataModelOutput:
+        out = self.metadata_model(input_ids=input_ids, attention_mask=attention_mask, output_attentions=output_attentions,
+                                  output_hidden_states=output_hidden_states)
+        p = out.pooler_output
+        emb = _ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight).view(*p.shape[:-1], -1)
+        return CM3PMetadataModelOutput(metadata_embeds=emb, last_hidden_state=out.last_hidden_state, hidden_states=None, attentions=None)
+
+
+class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
+    """Beatmap tower + projection, un-normalised (ref:cm3p/modeling_cm3p.py:1068-1128)."""
+
+    config_class = CM3PBeatmapConfig
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__(config)
+        self.beatmap_model = CM3PBeatmapTransformer(config)
+        self.beatmap_projection = nn.Linear(config.hidden_size, config.projection_dim, bias=False)
+        self.post_init()
+
+    def get_input_embeddings(self) -> nn.Module:
+        return self.beatmap_model.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.beatmap_model.set_input_embeddings(value)
+
+    def forward(self, input_ids: Optional[Tensor] = None, input_features: Optional[Tensor] = None,
+                attention_mask: Optional[Tensor] = None, position_ids: Optional[Tensor] = None,
+                inputs_embeds: Optional[Tensor] = None, output_attentions=None, output_hidden_states=None) -> CM3PBeatmapModelOutput:
+        out = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                 position_ids=position_ids, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
+                                 output_hidden_states=output_hidden_states)
+        emb = _ProjectFn.apply(out.pooler_output, self.beatmap_projection.weight)
+        return CM3PBeatmapModelOutput(beatmap_embeds=emb, pooler_output=out.pooler_output, last_hidden_state=out.last_hidden_state,
+                                      hidden_states=None, attentions=None, audio_model_output=out.audio_model_output)
+
+
+class CM3PForMaskedLM(CM3PPreTrainedModel):
+    """Beatmap tower + MLM head + ForMaskedLM loss (ref:cm3p/modeling_cm3p.py:1241-1377).  `sparse_prediction` (run the head on the
+    labelled positions only) changes the logits' shape and is not built."""
+
+    config_class = CM3PBeatmapConfig
+    _tied_weights_keys = {"decoder.weight": "beatmap_model.encoder.embeddings.tok_embeddings.weight"}
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__(config)
+        if getattr(config, "sparse_prediction", False):
+            raise NotImplementedError("CM3PForMaskedLM: sparse_prediction=True is outside this build's scope")
+        self.beatmap_model = CM3PBeatmapTransformer(config)
+        self.head = CM3PPredictionHead(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=config.decoder_bias)
+        self.post_init()
+
+    def get_output_embeddings(self):
+        return self.decoder
+
+    def set_output_embeddings(self, new_embeddings: nn.Linear):
+        self.decoder = new_embeddings
+
+    def get_input_embeddings(self) -> nn.Module:
+        return self.beatmap_model.get_input_embeddings()
+
+    def forward(self, input_ids: Optional[Tensor] = None, input_features: Optional[Tensor] = None,
+                attention_mask: Optional[Tensor] = None, sliding_window_mask=None, position_ids: Optional[Tensor] = None,
+                inputs_embeds: Optional[Tensor] = None, labels: Optional[Tensor] = None, indices=None, cu_seqlens=None,
+                max_seqlen=None, batch_size=None, seq_len=None, output_attentions=None, output_hidden_states=None, **kwargs):
+        from transformers.modeling_outputs import MaskedLMOutput
+
+        out = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                 position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices, cu_seqlens=cu_seqlens,
+                                 output_attentions=output_attentions, output_hidden_states=output_hidden_states, output_pooler=False)
+        hs = out.last_hidden_state
+        Bq, Sq, Hq = hs.shape
+        V = self.config.vocab_size
+        lp = _MLMHeadFn.apply(hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
+                              self.decoder.weight, self.decoder.bias, self.config.norm_eps)
+        logits = lp.view(Bq, Sq, -1)[..., :V]
+        loss = None
+        if labels is not None:
+            loss = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))
+        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+
+
 CM3PForBeatmapClassification = _later_row("CM3PForBeatmapClassification", "SURVEY.md §2: classifier variant")
-CM3PMetadataModelWithProjection = _later_row("CM3PMetadataModelWithProjection", "SURVEY.md §2: projection-only variant")
-CM3PBeatmapModelWithProjection = _later_row("CM3PBeatmapModelWithProjection", "SURVEY.md §2: projection-only variant")
 
 
 def _register():
@@ -662,6 +759,12 @@ def _register():
             AutoModel.register(cfg, cls)
         except ValueError:
             pass
+    try:
+        from transformers import AutoModelForMaskedLM
+
+        AutoModelForMaskedLM.register(CM3PBeatmapConfig, CM3PForMaskedLM)
+    except ValueError:
+        pass
 
 
 _register()

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the stand-alone model classes (CM3PBeatmapModelWithProjection, CM3PMetadataModelWithProjection,
+CM3PForMaskedLM), produced by running the REFERENCE classes on the CPU (fp32, sdpa) with the d64 weights.
+
+Build container only:   python tests/golden/make_golden_variants.py   -> tests/golden/variants_d64.safetensors
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+from safetensors.torch import load_file, save_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+from cases import CASES, make_inputs  # noqa: E402
+from make_golden import _shim_config  # noqa: E402  (also imports the reference package and asserts where it came from)
+
+from cm3p import CM3PConfig  # noqa: E402
+from cm3p.modeling_cm3p import CM3PBeatmapModelWithProjection, CM3PForMaskedLM, CM3PMetadataModelWithProjection  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(8)
+    name = "d64_mlm"
+    cfg = CM3PConfig(**CASES[name]["cfg"])
+    for sub in (cfg.metadata_config, cfg.beatmap_config, cfg.beatmap_config.audio_config):
+        _shim_config(sub)
+    weights = load_file(os.path.join(HERE, "weights_d64.safetensors"))
+    extra = {k[2:]: v for k, v in load_file(os.path.join(HERE, f"{name}.safetensors")).items() if k.startswith("w.")}
+    weights.update(extra)
+    inputs = make_inputs(name)
+    blob = {}
+
+    bm = CM3PBeatmapModelWithProjection._from_config(cfg.beatmap_config, attn_implementation="sdpa").float().train()
+    missing = bm.load_state_dict({k: v for k, v in weights.items() if k in bm.state_dict()}, strict=True)
+    out = bm(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"])
+    out.beatmap_embeds.square().sum().backward()
+    blob["bproj.beatmap_embeds"] = out.beatmap_embeds.detach().contiguous()
+    blob["bproj.grad.beatmap_projection.weight"] = bm.beatmap_projection.weight.grad.clone()
+    blob["bproj.grad.beatmap_model.encoder.layers.1.attn.Wqkv.weight"] = bm.beatmap_model.encoder.layers[1].attn.Wqkv.weight.grad.clone()
+
+    mm = CM3PMetadataModelWithProjection._from_config(cfg.metadata_config, attn_implementation="sdpa").float().train()
+    mm.load_state_dict({k: v for k, v in weights.items() if k in mm.state_dict()}, strict=True)
+    out = mm(input_ids=inputs["metadata_ids"], attention_mask=inputs["metadata_attention_mask"])
+    blob["mproj.metadata_embeds"] = out.metadata_embeds.detach().contiguous()
+
+    ml = CM3PForMaskedLM._from_config(cfg.beatmap_config, attn_implementation="sdpa").float().train()
+    sd = {k: v for k, v in weights.items() if k in ml.state_dict()}
+    print("ForMaskedLM keys missing from the weight file:", sorted(set(ml.state_dict()) - set(sd)))
+    ml.load_state_dict(sd, strict=False)
+    tied = ml.decoder.weight.data_ptr() == ml.beatmap_model.get_input_embeddings().weight.data_ptr()
+    print("decoder.weight tied to the token embeddings:", tied)
+    out = ml(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], labels=inputs["labels"])
+    out.loss.backward()
+    blob["mlm.loss"] = out.loss.detach().reshape(1)
+    blob["mlm.logits"] = out.logits.detach().contiguous()
+    blob["mlm.tied"] = torch.tensor([int(tied)])
+    blob["mlm.grad.head.dense.weight"] = ml.head.dense.weight.grad.clone()
+    blob["mlm.grad.decoder.weight"] = ml.decoder.weight.grad.clone()
+    blob["mlm.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"] = ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad.clone()
+    save_file(blob, os.path.join(HERE, "variants_d64.safetensors"))
+    for k, v in blob.items():
+        print(f"{k:70s} {tuple(v.shape)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -130,12 +130,24 @@ def test_unsupported_shapes_fail_loudly():
     assert {"head.dense.weight", "head.norm.weight", "decoder.weight", "decoder.bias"} <= set(m.state_dict())
 
 
-def test_later_rows_are_importable_but_not_built():
-    from cm3p_amd.modeling_cm3p import CM3PForBeatmapClassification, CM3PForMaskedLM
+def test_standalone_classes_and_the_one_later_row():
+    """The stand-alone classes carry the same parameter names as the matching parts of CM3PModel (so one checkpoint serves all);
+    the classifier variant is importable but not built."""
+    from cm3p_amd import CM3PConfig
+    from cm3p_amd.modeling_cm3p import (CM3PBeatmapModelWithProjection, CM3PForBeatmapClassification, CM3PForMaskedLM,
+                                        CM3PMetadataModelWithProjection)
 
-    for cls in (CM3PForMaskedLM, CM3PForBeatmapClassification):
-        with pytest.raises(NotImplementedError):
-            cls(None)
+    with pytest.raises(NotImplementedError):
+        CM3PForBeatmapClassification(None)
+    cfg = CM3PConfig(**CASES["d64_mlm"]["cfg"])
+    full = set(load_file(os.path.join(GOLD, "weights_d64.safetensors"))) | {"head.dense.weight", "head.norm.weight", "decoder.weight", "decoder.bias"}
+    for cls, c in ((CM3PBeatmapModelWithProjection, cfg.beatmap_config), (CM3PMetadataModelWithProjection, cfg.metadata_config),
+                   (CM3PForMaskedLM, cfg.beatmap_config)):
+        keys = set(cls(c).state_dict())
+        assert keys and keys <= full, sorted(keys - full)
+    cfg.beatmap_config.sparse_prediction = True
+    with pytest.raises(NotImplementedError):
+        CM3PForMaskedLM(cfg.beatmap_config)
 
 
 def test_cm3p_package_shim_resolves_like_train_py_imports():

@@ -339,3 +339,46 @@ def test_extraction_and_variation_eval_paths():
     assert big.logits_per_metadata.shape == (B, V * reps, B)
     assert torch.isfinite(big.logits_per_metadata).all() and torch.isfinite(big.loss)
     assert torch.equal(big.logits_per_metadata[:, :V], full.logits_per_metadata)
+
+
+# ------------------------------------------------------------------------------------------------- stand-alone classes
+def _load_into(model, name="d64_mlm"):
+    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
+    sd.update({k[2:]: v for k, v in load_file(os.path.join(GOLD, f"{name}.safetensors")).items() if k.startswith("w.")})
+    own = model.state_dict()
+    model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=True)
+    return model.to(DEV).train()
+
+
+def test_standalone_classes_match_reference_fixture():
+    """CM3PBeatmapModelWithProjection / CM3PMetadataModelWithProjection / CM3PForMaskedLM against outputs of the reference's own
+    classes (tests/golden/make_golden_variants.py): same state-dict keys as the matching parts of CM3PModel, un-normalised
+    projections, MLM logits / loss / gradients."""
+    from cm3p_amd import CM3PConfig
+    from cm3p_amd.modeling_cm3p import CM3PBeatmapModelWithProjection, CM3PForMaskedLM, CM3PMetadataModelWithProjection
+
+    gold = load_file(os.path.join(GOLD, "variants_d64.safetensors"))
+    blob = load_file(os.path.join(GOLD, "d64_mlm.safetensors"))
+    inp = _inputs(blob)
+    cfg = CM3PConfig(**CASES["d64_mlm"]["cfg"])
+
+    bm = _load_into(CM3PBeatmapModelWithProjection(cfg.beatmap_config))
+    out = bm(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"])
+    assert _rel(out.beatmap_embeds, gold["bproj.beatmap_embeds"]) <= 2e-2
+    out.beatmap_embeds.square().sum().backward()
+    assert _rel(bm.beatmap_projection.weight.grad, gold["bproj.grad.beatmap_projection.weight"]) <= 6e-2
+    assert _rel(bm.beatmap_model.encoder.layers[1].attn.Wqkv.weight.grad, gold["bproj.grad.beatmap_model.encoder.layers.1.attn.Wqkv.weight"]) <= 6e-2
+
+    mm = _load_into(CM3PMetadataModelWithProjection(cfg.metadata_config))
+    out = mm(input_ids=inp["metadata_ids"], attention_mask=inp["metadata_attention_mask"])
+    assert _rel(out.metadata_embeds, gold["mproj.metadata_embeds"]) <= 2e-2
+
+    ml = _load_into(CM3PForMaskedLM(cfg.beatmap_config))
+    assert int(gold["mlm.tied"].item()) == int(ml.decoder.weight.data_ptr() == ml.get_input_embeddings().weight.data_ptr())
+    out = ml(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], labels=inp["labels"])
+    assert abs(out.loss.item() - gold["mlm.loss"].item()) <= 3e-2
+    assert out.logits.shape == gold["mlm.logits"].shape and _rel(out.logits, gold["mlm.logits"]) <= 3e-2
+    out.loss.backward()
+    assert _rel(ml.head.dense.weight.grad, gold["mlm.grad.head.dense.weight"]) <= 6e-2
+    assert _rel(ml.decoder.weight.grad, gold["mlm.grad.decoder.weight"]) <= 6e-2
+    assert _rel(ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad, gold["mlm.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"]) <= 6e-2
