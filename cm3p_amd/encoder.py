@@ -320,17 +320,22 @@ class CM3PEncoder(nn.Module):
         dev = ref.device
 
         packed = None
-        if unpad and attention_mask is not None and input_ids is not None and audio_slot is None:
+        if unpad and attention_mask is not None and input_ids is not None:
             packed = self._plan_unpadded(attention_mask.reshape(B, S), position_ids)
 
         if packed is not None:
             idx, cu, max_s, n_valid, n_rows, pos = packed
             ids = input_ids.contiguous().view(-1)[idx]  # integer row selection (the reference's _unpad_cm3p_input)
+            slot_p = None
+            if audio_slot is not None:  # audio placeholders are valid tokens: their slot numbers travel with them
+                slot_p = audio_slot.view(-1)[idx]
             if n_rows != n_valid:  # alignment rows: one extra pseudo-sequence of pad tokens, no gradient flows into it
                 ids = torch.cat((ids, ids.new_zeros(n_rows - n_valid)))
+                if slot_p is not None:
+                    slot_p = torch.cat((slot_p, slot_p.new_full((n_rows - n_valid,), -1)))
             pad = self.embeddings.tok_embeddings.padding_idx
             x0 = _EmbedLNFn.apply(ids, self.embeddings.tok_embeddings.weight, self.embeddings.norm.weight, cfg.norm_eps,
-                                  -1 if pad is None else pad, None, None)
+                                  -1 if pad is None else pad, None if slot_p is None else slot_p.contiguous(), audio_rows)
         elif input_ids is not None:
             pad = self.embeddings.tok_embeddings.padding_idx
             x0 = _EmbedLNFn.apply(input_ids.contiguous().view(-1), self.embeddings.tok_embeddings.weight,

@@ -249,7 +249,7 @@ def test_two_rank_gathered_step_equals_single_process_global_batch():
 
 
 # ------------------------------------------------------------------------------------------------- unpadded execution
-@pytest.mark.parametrize("name", ["d64_mean_pad", "d64_mean_longpad", "d64_ragged", "d64_mlm"])
+@pytest.mark.parametrize("name", ["d64_mean_pad", "d64_mean_longpad", "d64_ragged", "d64_mlm", "d64_audio"])
 def test_unpadded_execution_matches_the_reference_fixture(name):
     """unpad_inputs=True packs the valid tokens (the reference's flash_attention_2 path, ref:cm3p/modeling_cm3p.py:911-931) and must
     give the reference's results on every VALID position, the same pooled outputs / loss / gradients (same tolerances as the
