@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -65,6 +65,7 @@ SIGNATURES = {
     "cm3p_scale_by": [_P, _P, _P, _L, _P],
     "cm3p_dot_f32": [_P, _P, _P, _L, _P],
     "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
+    "cm3p_pointwise_loss": [_P, _P, _P, _P, _L, _I, _P],
     "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P],
     "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _P],
     "cm3p_gather_rows_f32": [_P, _P, _P, _L, _I, _P],

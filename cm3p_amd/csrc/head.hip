@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256) void add_bias_kernel(float* __restrict__ x, co
     }
 }
 
+__global__ __launch_bounds__(256) void add_bias_scalar_kernel(float* __restrict__ x, const float* __restrict__ bias, int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) x[i] += bias[i % cols];
+}
+
 // partial[b, c] = sum over rows r = b, b + nblk, ... of x[r, c]; then out[c] = sum_b partial[b, c] (fixed order)
 __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows, int cols) {
     for (int c = threadIdx.x; c < cols; c += 256) {
@@ -206,9 +211,42 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, f
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + scale * s : scale * s;
 }
 
+// Mean element-wise losses of the classifier variant (ref:cm3p/modeling_cm3p.py:1196-1218): kind 0 = MSELoss, kind 1 =
+// BCEWithLogitsLoss.  out[0] = mean_i loss(x_i, y_i); dx[i] = d mean / d x_i.  One workgroup, fixed order: n is batch * labels.
+__global__ __launch_bounds__(256) void pointwise_loss_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                                             float* __restrict__ dx, int64_t n, int kind) {
+    __shared__ float red[4];
+    const float inv = 1.0f / (float)n;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float a = x[i], t = y[i];
+        float l, g;
+        if (kind == 0) {
+            const float d = a - t;
+            l = d * d;
+            g = 2.f * d;
+        } else {
+            // max(a, 0) - a t + log1p(exp(-|a|)): torch's numerically stable form (ATen binary_cross_entropy_with_logits)
+            l = fmaxf(a, 0.f) - a * t + log1pf(expf(-fabsf(a)));
+            g = 1.f / (1.f + expf(-a)) - t;
+        }
+        s += l;
+        if (dx) dx[i] = g * inv;
+    }
+    s = block_reduce(s, red, false);
+    if (threadIdx.x == 0) out[0] = s * inv;
+}
+
 }  // namespace
 
 extern "C" {
+
+int cm3p_pointwise_loss(const float* x, const float* y, float* out, float* dx, int64_t n, int kind, void* stream) {
+    CM3P_REQUIRE(x && y && out && n > 0 && (kind == 0 || kind == 1));
+    pointwise_loss_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(x, y, out, dx, n, kind);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
 
 int cm3p_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_rs, int64_t a_cs, int64_t b_rs,
                   int64_t b_cs, int64_t ldc, float alpha, int accumulate, void* stream) {
@@ -261,7 +299,14 @@ int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index,
 }
 
 int cm3p_add_bias_f32(float* x, const float* bias, int64_t rows, int cols, void* stream) {
-    CM3P_REQUIRE(x && bias && rows > 0 && cols > 0 && cols % 4 == 0);
+    CM3P_REQUIRE(x && bias && rows > 0 && cols > 0);
+    if (cols % 4 != 0 || !cm3p_aligned16(x) || !cm3p_aligned16(bias)) {  // small classifier heads (any number of labels)
+        int64_t blocks = (rows * cols + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        add_bias_scalar_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, rows, cols);
+        CM3P_LAUNCH_CHECK();
+        return CM3P_OK;
+    }
     int64_t blocks = (rows * (cols / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     add_bias_kernel<<<(int)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, rows, cols / 4);

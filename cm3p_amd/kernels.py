@@ -356,6 +356,14 @@ def colsum_f32(x: Tensor) -> Tensor:
     return out
 
 
+def pointwise_loss(x: Tensor, y: Tensor, kind: int):
+    """Mean MSE (kind 0) / BCE-with-logits (kind 1) of fp32 x against y -> (loss [1], dloss/dx)."""
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    call("cm3p_pointwise_loss", ptr(x), ptr(y), ptr(out), ptr(dx), x.numel(), kind, stream())
+    return out, dx
+
+
 def first_zero_index(classes: Tensor) -> Tensor:
     B, V = classes.shape
     idx = torch.empty((B,), dtype=torch.int64, device=classes.device)

@@ -640,16 +640,7 @@ class CM3PModel(CM3PPreTrainedModel):
                           metadata_model_output=metadata_outputs, beatmap_model_output=beatmap_outputs)
 
 
-# ----------------------------------------------------------------------------------------------- later rows (importable)
-def _later_row(name: str, row: str):
-    class _NotInThisBuild(CM3PPreTrainedModel):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"{name} is outside this build's scope ({row}); use the reference implementation for it")
-
-    _NotInThisBuild.__name__ = _NotInThisBuild.__qualname__ = name
-    return _NotInThisBuild
-
-
+# ----------------------------------------------------------------------------------------------- stand-alone variants
 class CM3PMetadataModelWithProjection(CM3PPreTrainedModel):
     """Metadata tower + projection, un-normalised (ref:cm3p/modeling_cm3p.py:1015-1065)."""
 
@@ -750,7 +741,86 @@ class CM3PForMaskedLM(CM3PPreTrainedModel):
         return MaskedLMOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
 
 
-CM3PForBeatmapClassification = _later_row("CM3PForBeatmapClassification", "SURVEY.md §2: classifier variant")
+class _AddBiasFn(torch.autograd.Function):
+    """x [rows, n] fp32 + bias [n]; backward: db = column sums."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, bias: Tensor):
+        ctx.bdtype = bias.dtype
+        return K.add_bias_(x.detach().clone().contiguous(), _f32(bias.detach()).contiguous())
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        dy = dy.contiguous()
+        return dy, K.colsum_f32(dy).to(ctx.bdtype)
+
+
+class _PointwiseLossFn(torch.autograd.Function):
+    """Mean MSELoss (kind 0) / BCEWithLogitsLoss (kind 1)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, y: Tensor, kind: int):
+        loss, dx = K.pointwise_loss(x.detach().contiguous(), y.detach().to(torch.float32).contiguous(), kind)
+        ctx.dx = dx
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return K.scale_by(ctx.dx, g.reshape(1).contiguous()), None, None
+
+
+@dataclass
+class BeatmapClassifierOutput(ModelOutput):
+    loss: Optional[torch.FloatTensor] = None
+    logits: Optional[torch.FloatTensor] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+
+class CM3PForBeatmapClassification(CM3PPreTrainedModel):
+    """Beatmap tower + linear classifier on the pooled output with the three HF loss flavours
+    (ref:cm3p/modeling_cm3p.py:1137-1225)."""
+
+    config_class = CM3PBeatmapConfig
+    base_model_prefix = "beatmap_model"
+
+    def __init__(self, config: CM3PBeatmapConfig):
+        super().__init__(config)
+        self.num_labels = config.num_labels
+        self.beatmap_model = CM3PBeatmapTransformer(config)
+        self.classifier = nn.Linear(config.hidden_size, config.num_labels) if config.num_labels > 0 else nn.Identity()
+        self.post_init()
+
+    def forward(self, input_ids: Optional[Tensor] = None, input_features: Optional[Tensor] = None,
+                attention_mask: Optional[Tensor] = None, position_ids: Optional[Tensor] = None,
+                inputs_embeds: Optional[Tensor] = None, labels: Optional[Tensor] = None, output_attentions=None,
+                output_hidden_states=None) -> BeatmapClassifierOutput:
+        out = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                 position_ids=position_ids, inputs_embeds=inputs_embeds, output_attentions=output_attentions,
+                                 output_hidden_states=output_hidden_states)
+        logits = out.pooler_output
+        if self.num_labels > 0:
+            logits = _AddBiasFn.apply(_ProjectFn.apply(out.pooler_output, self.classifier.weight), self.classifier.bias)
+        loss = None
+        if labels is not None:
+            labels = labels.to(logits.device)
+            if self.config.problem_type is None:  # the reference's (HF's) inference rule, :1198-1204
+                if self.num_labels == 1:
+                    self.config.problem_type = "regression"
+                elif self.num_labels > 1 and labels.dtype in (torch.long, torch.int):
+                    self.config.problem_type = "single_label_classification"
+                else:
+                    self.config.problem_type = "multi_label_classification"
+            if self.config.problem_type == "regression":
+                loss = _PointwiseLossFn.apply(logits.reshape(-1), labels.reshape(-1), 0)
+            elif self.config.problem_type == "single_label_classification":
+                n = logits.shape[0]
+                spec = [(0, n, self.num_labels, self.num_labels, 1, None, labels.reshape(-1).to(torch.int64).contiguous(), 1.0)]
+                loss = _CrossEntropySumFn.apply(spec, logits)
+            else:
+                loss = _PointwiseLossFn.apply(logits.reshape(-1), labels.reshape(-1), 1)
+        return BeatmapClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+
 
 
 def _register():
@@ -760,9 +830,10 @@ def _register():
         except ValueError:
             pass
     try:
-        from transformers import AutoModelForMaskedLM
+        from transformers import AutoModelForMaskedLM, AutoModelForSequenceClassification
 
         AutoModelForMaskedLM.register(CM3PBeatmapConfig, CM3PForMaskedLM)
+        AutoModelForSequenceClassification.register(CM3PBeatmapConfig, CM3PForBeatmapClassification)
     except ValueError:
         pass
 

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 4
+#define CM3P_ABI_VERSION 5
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -213,7 +213,7 @@ int cm3p_sum_f32(const float* x, float* out, int64_t n, float scale, int accumul
  *   row_stride (>= cols; the pad columns get zero gradient).  loss_rows[r] = 0 for ignored rows.  dlogits (may be NULL) is
  *   fully written: grad_scale * inv_count[0] * (softmax - onehot).
  * cm3p_inv_valid_count: inv_count[0] = 1 / max(#(target != ignore_index), 1) - the "mean" denominator, kept on the device.
- * cm3p_add_bias_f32: x[r, :] += bias (cols % 4 == 0).   cm3p_colsum_f32: out[c] = sum_r x[r, c] (fixed order; partial is a
+ * cm3p_add_bias_f32: x[r, :] += bias.   cm3p_colsum_f32: out[c] = sum_r x[r, c] (fixed order; partial is a
  *   [cm3p_colsum_blocks(rows), cols] workspace) - the decoder bias gradient. */
 int cm3p_cross_entropy_masked(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target,
                               int64_t ignore_index, float grad_scale, const float* inv_count, float* loss_rows, float* dlogits,
@@ -222,6 +222,11 @@ int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index,
 int cm3p_add_bias_f32(float* x, const float* bias, int64_t rows, int cols, void* stream);
 int cm3p_colsum_blocks(int64_t rows);
 int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, int cols, void* stream);
+
+/* Classifier variant (CM3PForBeatmapClassification, ref:cm3p/modeling_cm3p.py:1196-1218): mean MSELoss (kind 0) or
+ * BCEWithLogitsLoss (kind 1) over n elements; out[0] = loss, dx (may be NULL) = its gradient.  CrossEntropyLoss reuses
+ * cm3p_cross_entropy. */
+int cm3p_pointwise_loss(const float* x, const float* y, float* out, float* dx, int64_t n, int kind, void* stream);
 
 /* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
 int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);

@@ -20,7 +20,8 @@ from cases import CASES, make_inputs  # noqa: E402
 from make_golden import _shim_config  # noqa: E402  (also imports the reference package and asserts where it came from)
 
 from cm3p import CM3PConfig  # noqa: E402
-from cm3p.modeling_cm3p import CM3PBeatmapModelWithProjection, CM3PForMaskedLM, CM3PMetadataModelWithProjection  # noqa: E402
+from cm3p.modeling_cm3p import (CM3PBeatmapModelWithProjection, CM3PForBeatmapClassification, CM3PForMaskedLM,  # noqa: E402
+                                CM3PMetadataModelWithProjection)
 
 
 def main():
@@ -62,6 +63,32 @@ def main():
     blob["mlm.grad.head.dense.weight"] = ml.head.dense.weight.grad.clone()
     blob["mlm.grad.decoder.weight"] = ml.decoder.weight.grad.clone()
     blob["mlm.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"] = ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad.clone()
+    # classifier variant, the three loss flavours HF infers from num_labels / label dtype (ref:cm3p/modeling_cm3p.py:1196-1218)
+    g = torch.Generator().manual_seed(99)
+    B = inputs["input_ids"].shape[0]
+    for tag, nl, labels in (("cls_ce", 5, torch.randint(0, 5, (B,), generator=g)),
+                            ("cls_mse", 1, torch.randn(B, generator=g)),
+                            ("cls_bce", 4, (torch.rand(B, 4, generator=g) > 0.5).float())):
+        import copy
+        bc = copy.deepcopy(cfg.beatmap_config)
+        bc.num_labels = nl
+        bc.problem_type = None
+        cl = CM3PForBeatmapClassification._from_config(bc, attn_implementation="sdpa").float().train()
+        cl.load_state_dict({k: v for k, v in weights.items() if k in cl.state_dict()}, strict=False)
+        with torch.no_grad():
+            cl.classifier.weight.copy_(torch.randn(cl.classifier.weight.shape, generator=g) * 0.3)
+            cl.classifier.bias.copy_(torch.randn(cl.classifier.bias.shape, generator=g) * 0.1)
+        out = cl(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], labels=labels)
+        out.loss.backward()
+        blob[f"{tag}.labels"] = labels.contiguous()
+        blob[f"{tag}.w.classifier.weight"] = cl.classifier.weight.detach().clone()
+        blob[f"{tag}.w.classifier.bias"] = cl.classifier.bias.detach().clone()
+        blob[f"{tag}.loss"] = out.loss.detach().reshape(1)
+        blob[f"{tag}.logits"] = out.logits.detach().contiguous()
+        blob[f"{tag}.grad.classifier.weight"] = cl.classifier.weight.grad.clone()
+        blob[f"{tag}.grad.classifier.bias"] = cl.classifier.bias.grad.clone()
+        blob[f"{tag}.grad.beatmap_model.encoder.final_norm.weight"] = cl.beatmap_model.encoder.final_norm.weight.grad.clone()
+        print(tag, "problem_type ->", cl.config.problem_type, "loss", float(out.loss))
     save_file(blob, os.path.join(HERE, "variants_d64.safetensors"))
     for k, v in blob.items():
         print(f"{k:70s} {tuple(v.shape)}")

@@ -382,3 +382,35 @@ def test_standalone_classes_match_reference_fixture():
     assert _rel(ml.head.dense.weight.grad, gold["mlm.grad.head.dense.weight"]) <= 6e-2
     assert _rel(ml.decoder.weight.grad, gold["mlm.grad.decoder.weight"]) <= 6e-2
     assert _rel(ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad, gold["mlm.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"]) <= 6e-2
+
+
+@pytest.mark.parametrize("tag,num_labels", [("cls_ce", 5), ("cls_mse", 1), ("cls_bce", 4)])
+def test_classifier_variant_matches_reference_fixture(tag, num_labels):
+    """CM3PForBeatmapClassification: CrossEntropy / MSE / BCE-with-logits as HF infers them from num_labels and the label dtype
+    (ref:cm3p/modeling_cm3p.py:1196-1218), against the reference's own class."""
+    import copy
+
+    from cm3p_amd import CM3PConfig
+    from cm3p_amd.modeling_cm3p import CM3PForBeatmapClassification
+
+    gold = load_file(os.path.join(GOLD, "variants_d64.safetensors"))
+    blob = load_file(os.path.join(GOLD, "d64_mlm.safetensors"))
+    inp = _inputs(blob)
+    bc = copy.deepcopy(CM3PConfig(**CASES["d64_mlm"]["cfg"]).beatmap_config)
+    bc.num_labels = num_labels
+    bc.problem_type = None
+    model = CM3PForBeatmapClassification(bc)
+    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
+    sd = {k: v for k, v in sd.items() if k in model.state_dict()}
+    sd["classifier.weight"] = gold[f"{tag}.w.classifier.weight"]
+    sd["classifier.bias"] = gold[f"{tag}.w.classifier.bias"]
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    out = model(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"], labels=gold[f"{tag}.labels"].to(DEV))
+    assert out.logits.shape == gold[f"{tag}.logits"].shape
+    assert _rel(out.logits, gold[f"{tag}.logits"]) <= 3e-2
+    assert abs(out.loss.item() - gold[f"{tag}.loss"].item()) <= 3e-2
+    out.loss.backward()
+    assert _rel(model.classifier.weight.grad, gold[f"{tag}.grad.classifier.weight"]) <= 6e-2
+    assert _rel(model.classifier.bias.grad, gold[f"{tag}.grad.classifier.bias"]) <= 6e-2
+    assert _rel(model.beatmap_model.encoder.final_norm.weight.grad, gold[f"{tag}.grad.beatmap_model.encoder.final_norm.weight"]) <= 6e-2
