@@ -695,20 +695,33 @@ class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
                                       hidden_states=None, attentions=None, audio_model_output=out.audio_model_output)
 
 
+class _TakeRowsFn(torch.autograd.Function):
+    """x [R, H] fp32 -> x[idx] (boolean-mask row selection of the sparse MLM head); backward scatters into zeros."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, idx: Tensor):
+        ctx.idx, ctx.rows = idx, x.shape[0]
+        return K.gather_rows(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        return K.scatter_rows(dy.contiguous(), ctx.idx, ctx.rows), None
+
+
 class CM3PForMaskedLM(CM3PPreTrainedModel):
-    """Beatmap tower + MLM head + ForMaskedLM loss (ref:cm3p/modeling_cm3p.py:1241-1377).  `sparse_prediction` (run the head on the
-    labelled positions only) changes the logits' shape and is not built."""
+    """Beatmap tower + MLM head + ForMaskedLM loss (ref:cm3p/modeling_cm3p.py:1241-1377), including `sparse_prediction`
+    (head and decoder on the labelled positions only, :1349-1357)."""
 
     config_class = CM3PBeatmapConfig
     _tied_weights_keys = {"decoder.weight": "beatmap_model.encoder.embeddings.tok_embeddings.weight"}
 
     def __init__(self, config: CM3PBeatmapConfig):
         super().__init__(config)
-        if getattr(config, "sparse_prediction", False):
-            raise NotImplementedError("CM3PForMaskedLM: sparse_prediction=True is outside this build's scope")
         self.beatmap_model = CM3PBeatmapTransformer(config)
         self.head = CM3PPredictionHead(config)
         self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=config.decoder_bias)
+        self.sparse_prediction = bool(getattr(config, "sparse_prediction", False))
+        self.sparse_pred_ignore_index = int(getattr(config, "sparse_pred_ignore_index", -100))
         self.post_init()
 
     def get_output_embeddings(self):
@@ -732,9 +745,16 @@ class CM3PForMaskedLM(CM3PPreTrainedModel):
         hs = out.last_hidden_state
         Bq, Sq, Hq = hs.shape
         V = self.config.vocab_size
-        lp = _MLMHeadFn.apply(hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
+        rows = hs.reshape(Bq * Sq, Hq)
+        sparse = self.sparse_prediction and labels is not None
+        if sparse:  # keep the labelled tokens only (row selection by index; the count needs one host read, as in the reference)
+            labels = labels.reshape(-1)
+            idx = torch.nonzero(labels != self.sparse_pred_ignore_index).flatten()
+            rows = _TakeRowsFn.apply(rows, idx)
+            labels = labels[idx]
+        lp = _MLMHeadFn.apply(rows, self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
                               self.decoder.weight, self.decoder.bias, self.config.norm_eps)
-        logits = lp.view(Bq, Sq, -1)[..., :V]
+        logits = lp[..., :V] if sparse else lp.view(Bq, Sq, -1)[..., :V]
         loss = None
         if labels is not None:
             loss = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))

@@ -63,6 +63,20 @@ def main():
     blob["mlm.grad.head.dense.weight"] = ml.head.dense.weight.grad.clone()
     blob["mlm.grad.decoder.weight"] = ml.decoder.weight.grad.clone()
     blob["mlm.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"] = ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad.clone()
+    # sparse_prediction: head + decoder on the labelled positions only (ref:cm3p/modeling_cm3p.py:1349-1357)
+    import copy as _copy
+    sc = _copy.deepcopy(cfg.beatmap_config)
+    sc.sparse_prediction = True
+    sp = CM3PForMaskedLM._from_config(sc, attn_implementation="sdpa").float().train()
+    sp.load_state_dict({k: v for k, v in weights.items() if k in sp.state_dict()}, strict=False)
+    out = sp(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"], labels=inputs["labels"])
+    out.loss.backward()
+    blob["mlm_sparse.loss"] = out.loss.detach().reshape(1)
+    blob["mlm_sparse.logits"] = out.logits.detach().contiguous()
+    blob["mlm_sparse.grad.decoder.weight"] = sp.decoder.weight.grad.clone()
+    blob["mlm_sparse.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"] = sp.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad.clone()
+    print("sparse MLM logits", tuple(out.logits.shape), "loss", float(out.loss))
+
     # classifier variant, the three loss flavours HF infers from num_labels / label dtype (ref:cm3p/modeling_cm3p.py:1196-1218)
     g = torch.Generator().manual_seed(99)
     B = inputs["input_ids"].shape[0]

@@ -144,9 +144,6 @@ def test_standalone_classes_and_the_one_later_row():
                    (CM3PForMaskedLM, cfg.beatmap_config)):
         keys = set(cls(c).state_dict())
         assert keys and keys <= full, sorted(keys - full)
-    cfg.beatmap_config.sparse_prediction = True
-    with pytest.raises(NotImplementedError):
-        CM3PForMaskedLM(cfg.beatmap_config)
 
 
 def test_cm3p_package_shim_resolves_like_train_py_imports():
