@@ -90,16 +90,38 @@ def _bf16_weight(w: Tensor) -> Tensor:
 class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
-    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s")
+    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint")
 
 
 class _EncoderStackFn(torch.autograd.Function):
     """x0 [T,H] fp32 (already embedding-normed) + all layer weights -> final-normed hidden [T,H] fp32."""
 
     @staticmethod
-    def forward(ctx, geo: _Geometry, x0: Tensor, *weights: Tensor):
-        B, S, H, nh, L = geo.B, geo.S, geo.H, geo.nh, geo.L
+    def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
+        """One encoder layer on [T, H] rows: -> (x_out, activations needed by its backward)."""
+        w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb
+        B, S, nh = geo.B, geo.S, geo.nh
         scale = 64 ** -0.5
+        cos, sin = geo.rope[i]
+        if i == 0:
+            xn, mean_a, rstd_a = K.cast_bf16(x), None, None
+        else:
+            _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, want_stats)
+        qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
+        if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
+            o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
+        else:
+            o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
+        x_mid = K.linear_fwd(o, Wo_b, resid=x)
+        _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
+        h = K.linear_fwd(xn2, Wi_b)
+        g = K.geglu_fwd(h)
+        x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
+        return x_out, (x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g)
+
+    @staticmethod
+    def forward(ctx, geo: _Geometry, x0: Tensor, *weights: Tensor):
+        L = geo.L
         it = iter(weights)
         saved = []
         x = x0
@@ -108,24 +130,13 @@ class _EncoderStackFn(torch.autograd.Function):
             w_an = None if i == 0 else _f32(next(it))
             Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
             Wqkv_b, Wo_b, Wi_b, Wo2_b = (_bf16_weight(w) for w in (Wqkv, Wo, Wi, Wo2))
-            cos, sin = geo.rope[i]
-            if i == 0:
-                xn, mean_a, rstd_a = K.cast_bf16(x), None, None
-            else:
-                _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, geo.save)
-            qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
-            if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
-                o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
-            else:
-                o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
-            x_mid = K.linear_fwd(o, Wo_b, resid=x)
-            _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, geo.save)
-            h = K.linear_fwd(xn2, Wi_b)
-            g = K.geglu_fwd(h)
-            x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
+            wb = (w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b)
+            x_out, acts = _EncoderStackFn._layer_forward(geo, i, x, wb, geo.save)
             if geo.save:
-                saved.append((x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g))
-                wb_all.append((w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b))
+                # gradient checkpointing (ref: supports_gradient_checkpointing, TF GradientCheckpointingLayer): keep only the
+                # layer input; its activations are recomputed by the same kernels (bit-identical) in the backward pass
+                saved.append((x,) if geo.checkpoint else acts)
+                wb_all.append(wb)
             x = x_out
         w_fn = _f32(next(it))
         y, _, mean_f, rstd_f = K.layernorm_fwd(x, w_fn, geo.eps, True, False, geo.save)
@@ -150,7 +161,12 @@ class _EncoderStackFn(torch.autograd.Function):
         gx32, gx16, dw_fn = K.layernorm_bwd(dy, x_last, w_fn, mean_f, rstd_f, None, True, inplace=False)
         grads.append(dw_fn)
         for i in reversed(range(L)):
-            x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = ctx.saved[i]
+            if geo.checkpoint:
+                _, acts = _EncoderStackFn._layer_forward(geo, i, ctx.saved[i][0], ctx.wb[i], True)
+            else:
+                acts = ctx.saved[i]
+            x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = acts
+            del acts
             w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb[i]
             ctx.saved[i] = None  # release activations as we go
             # ---- MLP branch: x_out = x_mid + g Wo2^T
@@ -265,6 +281,7 @@ class CM3PEncoder(nn.Module):
         self.embeddings = CM3PEmbeddingParams(config)
         self.layers = nn.ModuleList([CM3PEncoderLayerParams(config, i) for i in range(config.num_hidden_layers)])
         self.final_norm = nn.LayerNorm(config.hidden_size, eps=config.norm_eps, bias=False)
+        self.gradient_checkpointing = False  # set by PreTrainedModel.gradient_checkpointing_enable()
         self._inv_freq_cache = {}
         # init roles (TF:...modeling_modernbert.py:372-386): 'in'/'embedding' std = initializer_range,
         # 'out' std = initializer_range / sqrt(2 L); consumed by CM3PPreTrainedModel._init_weights
@@ -349,6 +366,7 @@ class CM3PEncoder(nn.Module):
         geo.windows = [-1 if cfg.is_global_layer(i) else cfg.half_window for i in range(geo.L)]
         geo.key_mask = None
         geo.cu = None
+        geo.checkpoint = bool(self.gradient_checkpointing and self.training)
         geo.max_s = S
         if packed is not None:
             geo.B = cu.numel() - 1  # (+1 when alignment rows form a pseudo-sequence)

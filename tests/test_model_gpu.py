@@ -436,3 +436,25 @@ def test_sparse_prediction_mlm_matches_reference_fixture():
     out.loss.backward()
     assert _rel(ml.decoder.weight.grad, gold["mlm_sparse.grad.decoder.weight"]) <= 6e-2
     assert _rel(ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad, gold["mlm_sparse.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"]) <= 6e-2
+
+
+def test_gradient_checkpointing_recomputes_bit_identically():
+    """model.gradient_checkpointing_enable() (ref:cm3p/modeling_cm3p.py:257 supports_gradient_checkpointing): the stack keeps one
+    tensor per layer and recomputes the rest with the same deterministic kernels - losses and gradients are bit-identical."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    a, b = _build(name), _build(name)
+    b.gradient_checkpointing_enable()
+    assert b.beatmap_model.encoder.gradient_checkpointing and b.metadata_model.encoder.gradient_checkpointing
+    la, lb = a(**_inputs(blob)).loss, b(**_inputs(blob)).loss
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k in pa:
+        if pa[k].grad is None:
+            assert pb[k].grad is None, k
+        elif "tok_embeddings" in k:  # the embedding gradient is a float atomic scatter-add: order-dependent in the last bits
+            torch.testing.assert_close(pa[k].grad, pb[k].grad, rtol=1e-5, atol=1e-6)
+        else:
+            assert torch.equal(pa[k].grad, pb[k].grad), k
