@@ -90,7 +90,7 @@ def _bf16_weight(w: Tensor) -> Tensor:
 class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
-    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint")
+    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint", "collect")
 
 
 class _EncoderStackFn(torch.autograd.Function):
@@ -126,6 +126,7 @@ class _EncoderStackFn(torch.autograd.Function):
         saved = []
         x = x0
         wb_all = []
+        hiddens = [x0] if geo.collect else None  # output_hidden_states: the stack's input and every layer's output (detached)
         for i in range(L):
             w_an = None if i == 0 else _f32(next(it))
             Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
@@ -138,6 +139,8 @@ class _EncoderStackFn(torch.autograd.Function):
                 saved.append((x,) if geo.checkpoint else acts)
                 wb_all.append(wb)
             x = x_out
+            if hiddens is not None:
+                hiddens.append(x_out)
         w_fn = _f32(next(it))
         y, _, mean_f, rstd_f = K.layernorm_fwd(x, w_fn, geo.eps, True, False, geo.save)
         if geo.save:
@@ -146,10 +149,14 @@ class _EncoderStackFn(torch.autograd.Function):
             ctx.wb = wb_all
             ctx.final = (x, w_fn, mean_f, rstd_f)
             ctx.wdtypes = [w.dtype for w in weights]
+        if hiddens is not None:
+            hiddens = [h.detach().clone() if h is x0 else h for h in hiddens]  # never alias the differentiable input
+            ctx.mark_non_differentiable(*hiddens)
+            return (y, *hiddens)
         return y
 
     @staticmethod
-    def backward(ctx, dy: Tensor):
+    def backward(ctx, dy: Tensor, *_unused_hidden_grads):
         geo = ctx.geo
         B, S, nh, L = geo.B, geo.S, geo.nh, geo.L
         scale = 64 ** -0.5
@@ -320,8 +327,10 @@ class CM3PEncoder(nn.Module):
 
     def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 position_ids: Optional[Tensor] = None, inputs_embeds: Optional[Tensor] = None,
-                audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None, unpad: bool = False) -> Tensor:
-        """-> last_hidden_state (B, S, H) fp32.  Exactly one of input_ids / inputs_embeds.
+                audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None, unpad: bool = False,
+                output_hidden_states: bool = False):
+        """-> last_hidden_state (B, S, H) fp32 [, tuple of L+1 detached hidden states (the stack's input and every layer's output,
+        TF:...modeling_modernbert.py:457-470) when output_hidden_states].  Exactly one of input_ids / inputs_embeds.
 
         unpad: run the stack on the valid tokens only, packed back to back (what the reference's flash_attention_2 path does,
         ref:cm3p/modeling_cm3p.py:911-931); padding positions of the result are zero.  Used when the mask is a right-padded
@@ -367,6 +376,7 @@ class CM3PEncoder(nn.Module):
         geo.key_mask = None
         geo.cu = None
         geo.checkpoint = bool(self.gradient_checkpointing and self.training)
+        geo.collect = bool(output_hidden_states)
         geo.max_s = S
         if packed is not None:
             geo.B = cu.numel() - 1  # (+1 when alignment rows form a pseudo-sequence)
@@ -392,9 +402,16 @@ class CM3PEncoder(nn.Module):
         weights = self._stack_weights()
         geo.save = torch.is_grad_enabled() and (x0.requires_grad or any(w.requires_grad for w in weights))
         y = _EncoderStackFn.apply(geo, x0, *weights)
+        hiddens = None
+        if geo.collect:
+            y, *hiddens = y
+            if packed is not None:
+                hiddens = [K.scatter_rows(h[:n_valid].contiguous(), idx, B * S) for h in hiddens]
+            hiddens = tuple(h.view(B, S, H) for h in hiddens)
         if packed is not None:
             y = _PadRowsFn.apply(y, idx, n_valid, B * S)
-        return y.view(B, S, H)
+        y = y.view(B, S, H)
+        return (y, hiddens) if geo.collect else y
 
     @staticmethod
     def _plan_unpadded(mask: Tensor, position_ids: Optional[Tensor]):

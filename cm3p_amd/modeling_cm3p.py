@@ -354,8 +354,8 @@ class CM3PMetadataTransformer(nn.Module):
             raise ValueError("You have to specify input_ids")
         if indices is not None or cu_seqlens is not None:
             raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused HIP encoder")
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         _require_gpu(input_ids, "input_ids")
         is_3d = input_ids.dim() == 3
         B0 = input_ids.size(0)
@@ -363,13 +363,18 @@ class CM3PMetadataTransformer(nn.Module):
         if is_3d:  # (B, V, L) -> (B*V, L), ref:cm3p/modeling_cm3p.py:351-357
             ids2 = input_ids.reshape(-1, input_ids.size(-1))
             am2 = attention_mask.reshape(-1, attention_mask.size(-1)) if attention_mask is not None else None
-        h = self.encoder(input_ids=ids2, attention_mask=am2)
+        h = self.encoder(input_ids=ids2, attention_mask=am2, output_hidden_states=bool(output_hidden_states))
+        hiddens = None
+        if output_hidden_states:
+            h, hiddens = h
         pooled = _PoolFn.apply(h, am2, bool(self.config.cls_embed)) if output_pooler else None
         if is_3d:
             h = h.view(B0, -1, h.size(-2), h.size(-1))
             if pooled is not None:
                 pooled = pooled.view(B0, -1, pooled.size(-1))
-        return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=pooled, hidden_states=None, attentions=None)
+            if hiddens is not None:
+                hiddens = tuple(t.view(B0, -1, t.size(-2), t.size(-1)) for t in hiddens)
+        return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=None)
 
 
 class CM3PMultiModalProjector(nn.Module):
@@ -429,14 +434,16 @@ class CM3PBeatmapTransformer(nn.Module):
                 seq_len=None, output_attentions=None, output_hidden_states=None, output_pooler: bool = True) -> CM3PBeatmapModelOutput:
         if indices is not None or cu_seqlens is not None:
             raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused HIP encoder")
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         audio_out = None
+        ohs = bool(output_hidden_states)
         if inputs_embeds is not None:
             if input_features is not None:
                 raise NotImplementedError("input_features together with inputs_embeds is not supported")
             _require_gpu(inputs_embeds, "inputs_embeds")
-            h = self.encoder(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
+            h = self.encoder(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids,
+                             output_hidden_states=ohs)
         else:
             _require_gpu(input_ids, "input_ids")
             slot = rows = None
@@ -453,9 +460,12 @@ class CM3PBeatmapTransformer(nn.Module):
             unpad = self.unpad_inputs if self.unpad_inputs is not None else \
                 getattr(self.config, "_attn_implementation", None) == "flash_attention_2"
             h = self.encoder(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, audio_slot=slot,
-                             audio_rows=rows, unpad=bool(unpad))
+                             audio_rows=rows, unpad=bool(unpad), output_hidden_states=ohs)
+        hiddens = None
+        if ohs:
+            h, hiddens = h
         pooled = _PoolFn.apply(h, attention_mask, bool(self.config.cls_embed)) if output_pooler else None
-        return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=None, attentions=None,
+        return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=None,
                                       audio_model_output=audio_out)
 
 
@@ -664,7 +674,8 @@ class CM3PMetadataModelWithProjection(CM3PPreTrainedModel):
                                   output_hidden_states=output_hidden_states)
         p = out.pooler_output
         emb = _ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight).view(*p.shape[:-1], -1)
-        return CM3PMetadataModelOutput(metadata_embeds=emb, last_hidden_state=out.last_hidden_state, hidden_states=None, attentions=None)
+        return CM3PMetadataModelOutput(metadata_embeds=emb, last_hidden_state=out.last_hidden_state, hidden_states=out.hidden_states,
+                                       attentions=None)
 
 
 class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
@@ -692,7 +703,7 @@ class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
                                  output_hidden_states=output_hidden_states)
         emb = _ProjectFn.apply(out.pooler_output, self.beatmap_projection.weight)
         return CM3PBeatmapModelOutput(beatmap_embeds=emb, pooler_output=out.pooler_output, last_hidden_state=out.last_hidden_state,
-                                      hidden_states=None, attentions=None, audio_model_output=out.audio_model_output)
+                                      hidden_states=out.hidden_states, attentions=None, audio_model_output=out.audio_model_output)
 
 
 class _TakeRowsFn(torch.autograd.Function):
@@ -758,7 +769,7 @@ class CM3PForMaskedLM(CM3PPreTrainedModel):
         loss = None
         if labels is not None:
             loss = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))
-        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=None)
 
 
 class _AddBiasFn(torch.autograd.Function):
@@ -839,7 +850,7 @@ class CM3PForBeatmapClassification(CM3PPreTrainedModel):
                 loss = _CrossEntropySumFn.apply(spec, logits)
             else:
                 loss = _PointwiseLossFn.apply(logits.reshape(-1), labels.reshape(-1), 1)
-        return BeatmapClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+        return BeatmapClassifierOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=None)
 
 
 

@@ -458,3 +458,29 @@ def test_gradient_checkpointing_recomputes_bit_identically():
             torch.testing.assert_close(pa[k].grad, pb[k].grad, rtol=1e-5, atol=1e-6)
         else:
             assert torch.equal(pa[k].grad, pb[k].grad), k
+
+
+@pytest.mark.parametrize("unpad", [False, True])
+def test_output_hidden_states_match_the_reference_per_layer(unpad):
+    """output_hidden_states=True: L+1 tensors - the embedding output and every layer's output (TF:...modeling_modernbert.py:457-470) -
+    against the per-layer states the reference produced for d64_mean_pad; valid positions only (padded rows differ by design
+    between the padded and the unpadded execution)."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name).eval()
+    model.unpad_inputs = unpad
+    inp = _inputs(blob)
+    with torch.no_grad():
+        out = model(**inp, output_hidden_states=True)
+    hs = out.beatmap_model_output.hidden_states
+    L = CASES[name]["cfg"]["beatmap_config"]["num_hidden_layers"]
+    assert isinstance(hs, tuple) and len(hs) == L + 1
+    mask = blob["in.attention_mask"].bool()
+    assert _rel(hs[0].cpu()[mask], blob["beatmap_hidden_emb"][mask]) <= 2e-2
+    for li in range(L):
+        assert _rel(hs[li + 1].cpu()[mask], blob[f"beatmap_hidden_{li}"][mask]) <= 2e-2, li
+    assert len(out.metadata_model_output.hidden_states) == CASES[name]["cfg"]["metadata_config"]["num_hidden_layers"] + 1
+    # asking for the states must not change the result
+    with torch.no_grad():
+        plain = model(**inp)
+    assert torch.equal(plain.beatmap_embeds, out.beatmap_embeds)
