@@ -283,7 +283,8 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
     CM3P_REQUIRE(per_batch || M % S == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const RopeArgs rope{cos_tab, sin_tab, S, per_batch, rope_cols};
-    const bool big = (K % 64 == 0) && tiles_of(M, N, 256) >= 200;
+    // (the 256 x 256 kernel decides per tile whether its columns are rotated: the rotated range must end on a tile boundary)
+    const bool big = (K % 64 == 0) && (rope_cols % 256 == 0) && M < (int64_t(1) << 31) && tiles_of(M, N, 256) >= 200;
     int rc;
     if (big) rc = cm3p_gemm256_dispatch(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, 1, 1, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
     else rc = launch<true, true>(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);

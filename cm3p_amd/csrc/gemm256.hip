@@ -189,30 +189,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
         //  store-issue bound.)  `stage` now holds the next item's first k-tile (if any); the other 64 KiB are free.
         char* ebuf = smem + (stage ^ 1) * kStage;
-        if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
-            // rotate in registers, in fp32, before rounding: the wave's 64 columns are one head, dims d and d+32 are
-            // accumulator tiles j and j+2 of the same lane
-            if (n0 + wn * 64 < rope.ncols) {
-                // table row of token m is m (per-batch positions) or m mod S: one modulo per lane and tile, then the row groups
-                // (16 rows apart) advance it with a conditional subtract - eight 64-bit modulos per tile cost ~50 VGPRs of
-                // temporaries (spills) and a few hundred instructions
-                const int64_t mrow0 = m0 + wm * 128 + (lane & 15);
-                const int p0 = rope.per_batch ? 0 : (int)(mrow0 % rope.S);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int64_t m = mrow0 + i * 16;
-                    if (m > M - 1) m = M - 1;  // rows past the edge are never stored; any valid table row will do
-                    int pw = p0 + i * 16;
-                    if (rope.S >= 128) pw = pw >= rope.S ? pw - rope.S : pw;
-                    else pw %= rope.S;
-                    const int64_t prow = rope.per_batch ? m : (int64_t)pw;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
-                    __builtin_amdgcn_sched_barrier(0);  // keep the table loads of one row group at a time in flight (registers)
-                }
-            }
-        }
         if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
             constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
             uint16_t* C = static_cast<uint16_t*>(Cv);
@@ -229,11 +205,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                         }
                 }
                 lds_barrier();
+                bool rotated = false;
+                if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+                    // Rotary embedding at store time, on whole staged rows (apply_rotary_pos_emb on the bf16 projection, as the
+                    // reference's autocast path does): a work item is (row, head, 8 dims d..d+7 < 32) = the chunk pair (d, d+32);
+                    // one table read serves both.  Doing it in the accumulators instead cost 33 % of this GEMM (eight serialised
+                    // gather round trips per wave and ~50 spilled VGPRs).
+                    if (n0 < rope.ncols) {  // tiles are head-aligned: a tile lies entirely inside or outside the rotated columns
+                        rotated = true;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
-                    const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 8;
-                    if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(ebuf + r * kRow + ch * 16);
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tid + 512 * u, r = id >> 4, hd = (id >> 2) & 3, dc = id & 3;
+                            const int64_t m = m0 + pass * 64 + r, n = n0 + hd * 64 + dc * 8;
+                            if (m < M && n < N) {
+                                const int64_t prow = rope.per_batch ? m : (int64_t)((uint32_t)m % (uint32_t)rope.S);  // M < 2^31 (checked by the caller)
+                                const float* cr = rope.cos + prow * 32 + dc * 8;
+                                const float* sr = rope.sin + prow * 32 + dc * 8;
+                                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+                                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+                                const uint4 xa = *reinterpret_cast<const uint4*>(ebuf + r * kRow + (hd * 8 + dc) * 16);
+                                const uint4 xb = *reinterpret_cast<const uint4*>(ebuf + r * kRow + (hd * 8 + dc + 4) * 16);
+                                const uint32_t wa[4] = {xa.x, xa.y, xa.z, xa.w}, wb[4] = {xb.x, xb.y, xb.z, xb.w};
+                                const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                                const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                                uint32_t oa[4], ob[4];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const float a0 = bf16lo(wa[t]), a1 = bf16hi(wa[t]), b0 = bf16lo(wb[t]), b1 = bf16hi(wb[t]);
+                                    oa[t] = pack_bf16x2(a0 * cs[2 * t] - b0 * sn[2 * t], a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]);
+                                    ob[t] = pack_bf16x2(b0 * cs[2 * t] + a0 * sn[2 * t], b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]);
+                                }
+                                *reinterpret_cast<uint4*>(C + m * ldc + n) = uint4{oa[0], oa[1], oa[2], oa[3]};
+                                *reinterpret_cast<uint4*>(C + m * ldc + n + 32) = uint4{ob[0], ob[1], ob[2], ob[3]};
+                            }
+                        }
+                    }
+                }
+                if (!rotated) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
+                        const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 8;
+                        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(ebuf + r * kRow + ch * 16);
+                    }
                 }
                 lds_barrier();
             }

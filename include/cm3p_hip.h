@@ -93,9 +93,11 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
 
 /* Fused Wqkv projection + rotary embedding: qkv[M, N] (bf16) = x[M, K] Wqkv[N, K]^T with apply_rotary_pos_emb applied to the
- * first rope_cols (= 2H: the q and k thirds) columns in the fp32 accumulators before rounding
- * (TF:...modeling_modernbert.py:271-280).  cos/sin: [n_pos, 32] fp32 from cm3p_rope_table; token row m uses table row
- * m (per_batch != 0) or m % S.  Heads are 64 wide; N and rope_cols are multiples of 64. */
+ * first rope_cols (= 2H: the q and k thirds) columns (TF:...modeling_modernbert.py:271-280).  The 256 x 256 kernel rotates the
+ * bf16-rounded projection in fp32 while it stores the staged rows (what the reference's autocast path computes: rotary on the
+ * bf16 linear output); the 128 x 128 kernel for small shapes rotates the fp32 accumulators before rounding.  Both are inside
+ * the tolerance of the tests.  cos/sin: [n_pos, 32] fp32 from cm3p_rope_table; token row m uses table row m (per_batch != 0)
+ * or m % S.  Heads are 64 wide; N and rope_cols are multiples of 64. */
 int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, int64_t N, int64_t K, const float* cos_tab,
                        const float* sin_tab, int S, int per_batch, int rope_cols, void* stream);
 
