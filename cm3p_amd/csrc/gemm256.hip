@@ -254,6 +254,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         } else {
             constexpr int kRow = TN * 4 + 16;
             float* C = static_cast<float*>(Cv) + (int64_t)z * c_split_stride;
+            // residual rows of pass p+1 are requested before pass p's LDS round trip (16 VGPRs): a pass then waits for loads that
+            // have had a whole pass to arrive instead of issuing them and stalling on HBM latency eight times per tile
+            f32x4 rres[4];
+            auto load_resid = [&](int pass) {
+                if constexpr (EPI == CM3P_EPI_F32_RESID) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                        const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
+                        rres[u] = (m < M && n < N) ? *reinterpret_cast<const f32x4*>(R + m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            };
+            load_resid(0);
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {  // 32 rows per pass: waves with wm == pass/4, accumulator rows 2*(pass&3), +1
                 if (wm == (pass >> 2)) {
@@ -267,13 +281,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                         }
                 }
                 lds_barrier();
+                f32x4 rcur[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rcur[u] = rres[u];
+                if (pass < 7) load_resid(pass + 1);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
                     const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
                     if (m < M && n < N) {
                         f32x4 a = *reinterpret_cast<const f32x4*>(ebuf + r * kRow + ch * 16);
-                        if constexpr (EPI == CM3P_EPI_F32_RESID) a += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
+                        if constexpr (EPI == CM3P_EPI_F32_RESID) a += rcur[u];
                         *reinterpret_cast<f32x4*>(C + m * ldc + n) = a;
                     }
                 }
