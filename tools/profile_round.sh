@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the rocprofv3 passes whose summaries are committed under profiles/ (run from the repository root).
 #   bash tools/profile_round.sh r01
-# 1. kernel trace + stats of the judged command; 2. FETCH_SIZE and 3. WRITE_SIZE in separate counter-only passes
+# 1. kernel trace + stats of the judged command; 2. FETCH_SIZE, 3. WRITE_SIZE and 4. matrix-pipe busy cycles in separate counter-only passes
 # (MI355X_MICROARCH.md: never combine --pmc with other trace domains), turned into HBM bytes per launch by tools/pmc_traffic.py.
 set -e
 TAG=${1:-r01}
@@ -13,11 +13,15 @@ CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o out -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o out -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o out -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o out -- $CMD > $OUT/mfma.log 2>&1
 cd $R
 S=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 F=$(find $OUT/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/write -name "*counter_collection.csv" | head -1)
 cp "$S" $R/gpurun_out/${TAG}_c2_kernel_stats.csv
 python3 tools/pmc_traffic.py "$F" "$W" $R/gpurun_out/traffic_c2.json > $OUT/traffic.log
+U=$(find $OUT/mfma -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_mfma.py "$U" $R/gpurun_out/mfma_util_c2.json > $OUT/mfma_util.log
+cat $OUT/mfma_util.log | head -14
 tail -3 $OUT/stats.log
 head -12 $R/gpurun_out/${TAG}_c2_kernel_stats.csv | cut -c1-110
