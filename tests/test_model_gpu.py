@@ -484,3 +484,47 @@ def test_output_hidden_states_match_the_reference_per_layer(unpad):
     with torch.no_grad():
         plain = model(**inp)
     assert torch.equal(plain.beatmap_embeds, out.beatmap_embeds)
+
+
+def test_default_config_full_length_properties():
+    """BASELINE.json configs[1] architecture (ModernBERT-base towers) at the full beatmap length S = 4096 - too big for the CPU
+    oracle inside a test, so size-independent properties of the domain:
+      * rows of a batch never interact: changing row 1 leaves row 0's embedding bit-identical;
+      * right-padding + mask is transparent: a row's embedding does not depend on what the padded positions hold, and padded
+        and unpadded execution agree on it;
+      * the same batch twice gives the same bits (no atomics on the forward path)."""
+    from cm3p_amd import CM3PConfig, CM3PModel
+    from cm3p_amd.synthetic import synthetic_batch
+
+    cfg = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))
+    torch.manual_seed(0)
+    model = CM3PModel(cfg).to(DEV).eval()
+    B, S, L = 2, 4096, 256
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(cfg, B, S, L, seed=77, audio_T=None).items()}
+
+    def embeds(ids, mask, unpad=False):
+        model.unpad_inputs = unpad
+        with torch.no_grad():
+            return model(input_ids=ids, attention_mask=mask, return_loss=False).beatmap_embeds
+
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    e_a = embeds(ids, mask)
+    assert torch.equal(e_a, embeds(ids, mask))  # deterministic
+    ids_b = ids.clone()
+    ids_b[1] = torch.roll(ids[1], 17)
+    e_b = embeds(ids_b, mask)
+    assert torch.equal(e_b[0], e_a[0]) and not torch.equal(e_b[1], e_a[1])  # rows are independent
+
+    n1 = 3001  # row 1 is valid up to n1, the rest is padding
+    mask_c = mask.clone()
+    mask_c[1, n1:] = 0
+    ids_c = ids.clone()
+    ids_c[1, n1:] = 0
+    ids_d = ids.clone()
+    ids_d[1, n1:] = torch.randint(3, 100, (S - n1,), device=DEV)  # garbage under the mask
+    e_c, e_d = embeds(ids_c, mask_c), embeds(ids_d, mask_c)
+    assert torch.equal(e_c[0], e_a[0])  # the full row is untouched by its neighbour's padding
+    assert torch.equal(e_c[1], e_d[1])  # masked positions are invisible
+    e_u = embeds(ids_c, mask_c, unpad=True)
+    assert _rel(e_u, e_c) <= 5e-3  # packed vs padded execution (different tile alignment for row 1 only)
+    assert torch.equal(e_u[0], e_c[0])  # row 0 starts at packed row 0: same tiles, same bits
