@@ -362,40 +362,14 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// delta[b, h, q] = sum_d dO[q, d] * O[q, d]
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int64_t T, int S, int nh, int packed) {
-    const int64_t total = T * nh * 8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total + 7; i += (int64_t)gridDim.x * 256) {
-        const bool ok = i < total;
-        const int64_t row = ok ? i >> 3 : 0;  // (token, head)
-        const int c = (int)(i & 7);
-        float s = 0.f;
-        if (ok) {
-            const uint4 a = *reinterpret_cast<const uint4*>(o + row * 64 + c * 8);
-            const uint4 g = *reinterpret_cast<const uint4*>(d_o + row * 64 + c * 8);
-            s = bf16lo(a.x) * bf16lo(g.x) + bf16hi(a.x) * bf16hi(g.x) + bf16lo(a.y) * bf16lo(g.y) + bf16hi(a.y) * bf16hi(g.y) +
-                bf16lo(a.z) * bf16lo(g.z) + bf16hi(a.z) * bf16hi(g.z) + bf16lo(a.w) * bf16lo(g.w) + bf16hi(a.w) * bf16hi(g.w);
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (ok && c == 0) {
-            const int64_t tok = row / nh;
-            const int h = (int)(row % nh);
-            delta[packed ? (int64_t)h * T + tok : ((tok / S) * nh + h) * S + tok % S] = s;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// dQ: same geometry as the forward.  LDS per stage: K image (row + transposed reads) + V image + mask bytes.
+// dQ (and delta[b, h, q] = sum_d dO[q, d] * O[q, d], which it computes for its own rows and publishes for the dK/dV kernel):
+// same geometry as the forward.  LDS per stage: K image (row + transposed reads) + V image + mask bytes.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDqStage = 2 * 8192 + 64 + 16;  // K image, V image, mask bytes, all-valid flag
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
+                                                             float* __restrict__ delta,
                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
                                                              int Smax, int nh, int window, float scale,
                                                              const float* __restrict__ rope_cos,
@@ -428,7 +402,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     }
     const int64_t stat = sv.stat0 + qrow_c;
     const float lse2 = lse[stat] * kLog2e;  // +inf for rows with no visible key -> p = 0
-    const float dlt = delta[stat];
+    // delta[q] = sum_d dO[q, d] O[q, d]: this lane holds half of its query's dO row already; the other half sits 32 lanes
+    // away.  Written out for the dK/dV kernel, which runs after this one (no separate delta launch, one less pass over dO).
+    float dlt = 0.f;
+    {
+        const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(obase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt += (float)of[j] * (float)dof[s][j];
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (hh == 0 && qrow < S) delta[stat] = dlt;
+    }
 
     const int Q1 = min(S, Q0 + 128) - 1;
     int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
@@ -739,13 +726,8 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
                            const float* sin_tab, int64_t pos_batch_stride, VarLen vl, hipStream_t s) {
-    const int64_t T = vl.cu ? vl.total : (int64_t)B * S;
-    int64_t blocks = (T * nh * 8 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    attn_delta_kernel<<<(int)blocks, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, T, S, nh, vl.cu ? 1 : 0);
-    if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
                                                        key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
     if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,

@@ -182,7 +182,7 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
     call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(key_mask), B, S, nh, window, scale,
-         ptr(cos), ptr(sin), S if per_batch else 0, stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
+         ptr(cos), ptr(sin), S if per_batch else 0, stream(), tag="attn_bwd(dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
     return dqkv
 
 
@@ -203,7 +203,7 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
     call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(cu), B, max_s, qkv.shape[0], nh,
-         window, scale, ptr(cos), ptr(sin), stream(), tag="attn_bwd(delta+dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+         window, scale, ptr(cos), ptr(sin), stream(), tag="attn_bwd(dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
     return dqkv
 
 
