@@ -221,7 +221,7 @@ def main():
     if world > 1:
         model.gather_negatives = True
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
-                                                               bucket_cap_mb=128)
+                                                               bucket_cap_mb=32)  # per-layer autograd nodes: buckets fill (and reduce) while backward runs
     batch = make_batch(config, w, rank, device)
     if args.unpad:
         model.unpad_inputs = True

@@ -5,8 +5,9 @@
     embeddings.tok_embeddings.weight, embeddings.norm.weight, layers.N.{attn_norm,mlp_norm}.weight,
     layers.N.attn.{Wqkv,Wo}.weight, layers.N.mlp.{Wi,Wo}.weight, final_norm.weight
 The nn.Linear / nn.LayerNorm / nn.Embedding members are parameter containers only; their torch forward is never
-called.  The whole layer stack is ONE autograd node (`_EncoderStackFn`) whose forward and backward are sequences of
-C-ABI launches (cm3p_amd/kernels.py), restating TF:models/modernbert/modeling_modernbert.py:262-333,434-478:
+called.  Every encoder layer is ONE autograd node (`_EncoderLayerFn`; `_FinalNormFn` closes the stack) whose forward and
+backward are sequences of C-ABI launches (cm3p_amd/kernels.py), restating
+TF:models/modernbert/modeling_modernbert.py:262-333,434-478:
 
     per layer:  xn = LN(x) [identity for layer 0] -> qkv = xn Wqkv^T -> RoPE(q,k) -> flash attention (global, or
                 |i-j| <= 64 band; key padding) -> x += o Wo^T -> xn = LN(x) -> h = xn Wi^T -> g = gelu(h[:I]) * h[I:]
@@ -90,127 +91,151 @@ def _bf16_weight(w: Tensor) -> Tensor:
 class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
-    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint", "collect")
+    __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint",
+                 "handoff")
 
 
-class _EncoderStackFn(torch.autograd.Function):
-    """x0 [T,H] fp32 (already embedding-normed) + all layer weights -> final-normed hidden [T,H] fp32."""
+def _hand_upstream(geo: _Geometry, gx32: Tensor, gx16: Optional[Tensor]) -> None:
+    """A node's backward leaves the bf16 twin of the fp32 gradient it returns here; the node below (the next one the autograd
+    engine runs on this chain) picks it up instead of re-reading 4 bytes per element to cast it again."""
+    geo.handoff = (gx32, gx16)
+
+
+def _take_from_downstream(geo: _Geometry, dy: Tensor):
+    """-> (fp32 gradient this node may update in place, its bf16 twin).  The fast path applies when `dy` is exactly the tensor
+    the node above handed up (nothing else consumed that activation, so autograd passed it through untouched); the handoff
+    keeps that tensor alive, so an equal address cannot be a recycled allocation.  Anything else (a hook, a second consumer)
+    gets a private copy and a fresh cast."""
+    h, geo.handoff = geo.handoff, None
+    if h is not None and h[1] is not None and h[0].data_ptr() == dy.data_ptr() and h[0].shape == dy.shape and dy.dtype == torch.float32 \
+            and dy.is_contiguous():
+        return h[0], h[1]
+    g = dy.float().contiguous()
+    if g.data_ptr() == dy.data_ptr():
+        g = g.clone()
+    return g, K.cast_bf16(g)
+
+
+def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
+    """One encoder layer on [T, H] rows: -> (x_out, activations needed by its backward)."""
+    w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb
+    B, S, nh = geo.B, geo.S, geo.nh
+    scale = 64 ** -0.5
+    cos, sin = geo.rope[i]
+    if i == 0:
+        xn, mean_a, rstd_a = K.cast_bf16(x), None, None
+    else:
+        _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, want_stats)
+    qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
+    if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
+        o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
+    else:
+        o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
+    x_mid = K.linear_fwd(o, Wo_b, resid=x)
+    _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
+    h = K.linear_fwd(xn2, Wi_b)
+    g = K.geglu_fwd(h)
+    x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
+    return x_out, (x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g)
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    """One ModernBERT encoder layer (TF:...modeling_modernbert.py:318-333): x [T,H] fp32 + its weights -> x_out [T,H] fp32.
+
+    One autograd node per layer, so a layer's weight gradients reach their parameters (and a DistributedDataParallel
+    bucket's all-reduce starts) while the layers below are still in backward.  The fp32 residual-stream gradient travels
+    through autograd; its bf16 twin - what the next dgrad / wgrad GEMMs read - travels beside it (_hand_upstream)."""
 
     @staticmethod
-    def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
-        """One encoder layer on [T, H] rows: -> (x_out, activations needed by its backward)."""
-        w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb
+    def forward(ctx, geo: _Geometry, i: int, x: Tensor, *weights: Tensor):
+        it = iter(weights)
+        w_an = None if i == 0 else _f32(next(it))
+        Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
+        wb = (w_an, *(_bf16_weight(w) for w in (Wqkv, Wo)), w_mn, *(_bf16_weight(w) for w in (Wi, Wo2)))
+        x_out, acts = _layer_forward(geo, i, x, wb, geo.save)
+        if geo.save:
+            # gradient checkpointing (ref: supports_gradient_checkpointing, TF GradientCheckpointingLayer): keep only the
+            # layer input; its activations are recomputed by the same kernels (bit-identical) in the backward pass
+            ctx.saved = (x,) if geo.checkpoint else acts
+            ctx.geo, ctx.i, ctx.wb = geo, i, wb
+            ctx.wdtypes = [w.dtype for w in weights]
+        return x_out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        geo, i = ctx.geo, ctx.i
         B, S, nh = geo.B, geo.S, geo.nh
         scale = 64 ** -0.5
-        cos, sin = geo.rope[i]
+        need = ctx.needs_input_grad  # (geo, i, x, *weights)
+        need_w = list(need[3:])
         if i == 0:
-            xn, mean_a, rstd_a = K.cast_bf16(x), None, None
+            need_w.insert(0, False)  # (no attn_norm in layer 0)
+        n_an, n_qkv, n_o, n_mn, n_i, n_o2 = need_w
+        gx32, gx16 = _take_from_downstream(geo, dy)
+        if geo.checkpoint:
+            _, acts = _layer_forward(geo, i, ctx.saved[0], ctx.wb, True)
         else:
-            _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, want_stats)
-        qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
-        if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
-            o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
+            acts = ctx.saved
+        x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = acts
+        del acts
+        w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb
+        ctx.saved = ctx.wb = None  # release activations as we go
+        # ---- MLP branch: x_out = x_mid + g Wo2^T
+        dg = K.linear_dgrad(gx16, Wo2_b)
+        dWo2 = K.linear_wgrad(gx16, g) if n_o2 else None
+        dh = K.geglu_bwd(dg, h)
+        del dg, g
+        dxn2 = K.linear_dgrad(dh, Wi_b)
+        dWi = K.linear_wgrad(dh, xn2) if n_i else None
+        del dh, h, xn2
+        gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True)
+        del dxn2, x_mid
+        # ---- attention branch: x_mid = x + o Wo^T
+        do = K.linear_dgrad(gx16, Wo_b)
+        dWo = K.linear_wgrad(gx16, o) if n_o else None
+        # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
+        if geo.cu is not None:
+            dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i])
         else:
-            o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
-        x_mid = K.linear_fwd(o, Wo_b, resid=x)
-        _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
-        h = K.linear_fwd(xn2, Wi_b)
-        g = K.geglu_fwd(h)
-        x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
-        return x_out, (x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g)
+            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
+        del do, o, qkv
+        dWqkv = K.linear_wgrad(dqkv, xn) if n_qkv else None
+        if i == 0:
+            dw_an = None
+            if need[2]:
+                dxn = K.linear_dgrad(dqkv, Wqkv_b)
+                gx32, _ = K.add_f32(gx32, dxn, want_bf16=False)
+            _hand_upstream(geo, gx32, None)
+        elif need[2] or n_an:
+            dxn = K.linear_dgrad(dqkv, Wqkv_b)
+            gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True)
+            _hand_upstream(geo, gx32, gx16)
+        else:  # everything below this layer is frozen: the chain ends here
+            dw_an = None
+        grads = [dWqkv, dWo, dw_mn, dWi, dWo2] if i == 0 else [dw_an, dWqkv, dWo, dw_mn, dWi, dWo2]
+        out = [(gw if gw.dtype == dt else gw.to(dt)) if (nd and gw is not None) else None for gw, dt, nd in zip(grads, ctx.wdtypes, need[3:])]
+        return (None, None, gx32 if need[2] else None, *out)
+
+
+class _FinalNormFn(torch.autograd.Function):
+    """final_norm of the stack (TF:...modeling_modernbert.py:472): x [T,H] fp32 -> LayerNorm(x) fp32; its backward starts the
+    chain of bf16 gradient twins."""
 
     @staticmethod
-    def forward(ctx, geo: _Geometry, x0: Tensor, *weights: Tensor):
-        L = geo.L
-        it = iter(weights)
-        saved = []
-        x = x0
-        wb_all = []
-        hiddens = [x0] if geo.collect else None  # output_hidden_states: the stack's input and every layer's output (detached)
-        for i in range(L):
-            w_an = None if i == 0 else _f32(next(it))
-            Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
-            Wqkv_b, Wo_b, Wi_b, Wo2_b = (_bf16_weight(w) for w in (Wqkv, Wo, Wi, Wo2))
-            wb = (w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b)
-            x_out, acts = _EncoderStackFn._layer_forward(geo, i, x, wb, geo.save)
-            if geo.save:
-                # gradient checkpointing (ref: supports_gradient_checkpointing, TF GradientCheckpointingLayer): keep only the
-                # layer input; its activations are recomputed by the same kernels (bit-identical) in the backward pass
-                saved.append((x,) if geo.checkpoint else acts)
-                wb_all.append(wb)
-            x = x_out
-            if hiddens is not None:
-                hiddens.append(x_out)
-        w_fn = _f32(next(it))
-        y, _, mean_f, rstd_f = K.layernorm_fwd(x, w_fn, geo.eps, True, False, geo.save)
+    def forward(ctx, geo: _Geometry, x: Tensor, norm_w: Tensor):
+        w = _f32(norm_w.detach())
+        y, _, mean, rstd = K.layernorm_fwd(x, w, geo.eps, True, False, geo.save)
         if geo.save:
-            ctx.geo = geo
-            ctx.saved = saved
-            ctx.wb = wb_all
-            ctx.final = (x, w_fn, mean_f, rstd_f)
-            ctx.wdtypes = [w.dtype for w in weights]
-        if hiddens is not None:
-            hiddens = [h.detach().clone() if h is x0 else h for h in hiddens]  # never alias the differentiable input
-            ctx.mark_non_differentiable(*hiddens)
-            return (y, *hiddens)
+            ctx.geo, ctx.pack, ctx.wdtype = geo, (x, w, mean, rstd), norm_w.dtype
         return y
 
     @staticmethod
-    def backward(ctx, dy: Tensor, *_unused_hidden_grads):
-        geo = ctx.geo
-        B, S, nh, L = geo.B, geo.S, geo.nh, geo.L
-        scale = 64 ** -0.5
-        need = ctx.needs_input_grad  # (geo, x0, *weights)
-        grads = []  # collected in reverse weight order
-
-        x_last, w_fn, mean_f, rstd_f = ctx.final
-        dy = dy.contiguous()
-        gx32, gx16, dw_fn = K.layernorm_bwd(dy, x_last, w_fn, mean_f, rstd_f, None, True, inplace=False)
-        grads.append(dw_fn)
-        for i in reversed(range(L)):
-            if geo.checkpoint:
-                _, acts = _EncoderStackFn._layer_forward(geo, i, ctx.saved[i][0], ctx.wb[i], True)
-            else:
-                acts = ctx.saved[i]
-            x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = acts
-            del acts
-            w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb[i]
-            ctx.saved[i] = None  # release activations as we go
-            # ---- MLP branch: x_out = x_mid + g Wo2^T
-            dg = K.linear_dgrad(gx16, Wo2_b)
-            dWo2 = K.linear_wgrad(gx16, g)
-            dh = K.geglu_bwd(dg, h)
-            del dg, g
-            dxn2 = K.linear_dgrad(dh, Wi_b)
-            dWi = K.linear_wgrad(dh, xn2)
-            del dh, h, xn2
-            gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True)
-            del dxn2, x_mid
-            # ---- attention branch: x_mid = x + o Wo^T
-            do = K.linear_dgrad(gx16, Wo_b)
-            dWo = K.linear_wgrad(gx16, o)
-            # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
-            if geo.cu is not None:
-                dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i])
-            else:
-                dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
-            del do, o, qkv
-            dxn = K.linear_dgrad(dqkv, Wqkv_b)
-            dWqkv = K.linear_wgrad(dqkv, xn)
-            del dqkv, xn
-            if i == 0:
-                gx32, _ = K.add_f32(gx32, dxn, want_bf16=False)
-                grads.extend([dWo2, dWi, dw_mn, dWo, dWqkv])
-            else:
-                gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True)
-                grads.extend([dWo2, dWi, dw_mn, dWo, dWqkv, dw_an])
-            del dxn
-        grads.reverse()
-        out = []
-        for gw, dtype, needed in zip(grads, ctx.wdtypes, need[2:]):
-            out.append((gw if gw.dtype == dtype else gw.to(dtype)) if needed else None)
-        ctx.saved = ctx.wb = ctx.final = None
-        return (None, gx32 if need[1] else None, *out)
+    def backward(ctx, dy: Tensor):
+        x, w, mean, rstd = ctx.pack
+        gx32, gx16, dw = K.layernorm_bwd(dy.contiguous(), x, w, mean, rstd, None, True, inplace=False)
+        ctx.pack = None
+        _hand_upstream(ctx.geo, gx32, gx16)
+        return None, gx32 if ctx.needs_input_grad[1] else None, dw.to(ctx.wdtype) if ctx.needs_input_grad[2] else None
 
 
 class _EmbedLNFn(torch.autograd.Function):
@@ -317,12 +342,11 @@ class CM3PEncoder(nn.Module):
         return self._inv_freq_cache[key]
 
     def _stack_weights(self):
+        """Per layer: [attn_norm (layers > 0)], Wqkv, Wo, mlp_norm, Wi, Wo(mlp) - the argument order of _EncoderLayerFn."""
         ws = []
         for i, layer in enumerate(self.layers):
-            if i > 0:
-                ws.append(layer.attn_norm.weight)
-            ws += [layer.attn.Wqkv.weight, layer.attn.Wo.weight, layer.mlp_norm.weight, layer.mlp.Wi.weight, layer.mlp.Wo.weight]
-        ws.append(self.final_norm.weight)
+            w = [layer.attn_norm.weight] if i > 0 else []
+            ws.append(w + [layer.attn.Wqkv.weight, layer.attn.Wo.weight, layer.mlp_norm.weight, layer.mlp.Wi.weight, layer.mlp.Wo.weight])
         return ws
 
     def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
@@ -376,7 +400,6 @@ class CM3PEncoder(nn.Module):
         geo.key_mask = None
         geo.cu = None
         geo.checkpoint = bool(self.gradient_checkpointing and self.training)
-        geo.collect = bool(output_hidden_states)
         geo.max_s = S
         if packed is not None:
             geo.B = cu.numel() - 1  # (+1 when alignment rows form a pseudo-sequence)
@@ -400,18 +423,25 @@ class CM3PEncoder(nn.Module):
                 tables[is_global] = K.rope_table(pos_tok, self._inv_freq(theta, dev))
         geo.rope = [tables[cfg.is_global_layer(i)] for i in range(geo.L)]
         weights = self._stack_weights()
-        geo.save = torch.is_grad_enabled() and (x0.requires_grad or any(w.requires_grad for w in weights))
-        y = _EncoderStackFn.apply(geo, x0, *weights)
-        hiddens = None
-        if geo.collect:
-            y, *hiddens = y
+        geo.save = torch.is_grad_enabled() and (x0.requires_grad or self.final_norm.weight.requires_grad
+                                                or any(w.requires_grad for ws in weights for w in ws))
+        geo.handoff = None
+        # output_hidden_states: the stack's input and every layer's output (TF:...modeling_modernbert.py:457-470), detached
+        hiddens = [x0.detach()] if output_hidden_states else None
+        x = x0
+        for i in range(geo.L):
+            x = _EncoderLayerFn.apply(geo, i, x, *weights[i])
+            if hiddens is not None:
+                hiddens.append(x.detach())
+        y = _FinalNormFn.apply(geo, x, self.final_norm.weight)
+        if hiddens is not None:
             if packed is not None:
                 hiddens = [K.scatter_rows(h[:n_valid].contiguous(), idx, B * S) for h in hiddens]
             hiddens = tuple(h.view(B, S, H) for h in hiddens)
         if packed is not None:
             y = _PadRowsFn.apply(y, idx, n_valid, B * S)
         y = y.view(B, S, H)
-        return (y, hiddens) if geo.collect else y
+        return (y, hiddens) if output_hidden_states else y
 
     @staticmethod
     def _plan_unpadded(mask: Tensor, position_ids: Optional[Tensor]):

@@ -294,7 +294,7 @@ class _AddScaledFn(torch.autograd.Function):
 class CM3PPreTrainedModel(PreTrainedModel):
     config_class = CM3PConfig
     base_model_prefix = "cm3p"
-    supports_gradient_checkpointing = True  # per-layer recompute inside the fused stack (encoder._EncoderStackFn)
+    supports_gradient_checkpointing = True  # per-layer recompute inside encoder._EncoderLayerFn
     _supports_flash_attn_2 = True
     _supports_flash_attn = True
     _supports_sdpa = True

@@ -460,6 +460,73 @@ def test_gradient_checkpointing_recomputes_bit_identically():
             assert torch.equal(pa[k].grad, pb[k].grad), k
 
 
+def test_layer_gradients_are_delivered_while_lower_layers_are_still_in_backward():
+    """Each encoder layer is its own autograd node: when the top layer's weight gradient lands on its parameter the bottom
+    layer's has not been produced yet - this is what lets DistributedDataParallel start a bucket's all-reduce under the
+    rest of the backward pass."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name)
+    layers = model.beatmap_model.encoder.layers
+    seen = {}
+
+    def top_layer_done(p):
+        seen["bottom_pending"] = layers[0].attn.Wqkv.weight.grad is None
+
+    layers[len(layers) - 1].mlp.Wo.weight.register_post_accumulate_grad_hook(top_layer_done)
+    order = []
+
+    def note(i):
+        def hook(p):
+            order.append(i)
+        return hook
+
+    for i, layer in enumerate(layers):
+        layer.attn.Wqkv.weight.register_post_accumulate_grad_hook(note(i))
+    model(**_inputs(blob)).loss.backward()
+    assert seen == {"bottom_pending": True}
+    assert order == list(reversed(range(len(layers))))
+
+
+def test_frozen_weights_get_no_gradient_and_leave_the_others_unchanged():
+    """ref:train.py:34,317-321 freezes towers / subsets of parameters: a frozen weight's gradient GEMM is skipped, the rest
+    of the gradients are bit-identical to the all-trainable run, and the chain stops below the lowest trainable layer."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    a, b = _build(name), _build(name)
+    enc = b.beatmap_model.encoder
+    frozen = [enc.layers[1].mlp.Wi.weight, enc.layers[2].attn_norm.weight, enc.layers[0].attn.Wqkv.weight]
+    for p in frozen:
+        p.requires_grad_(False)
+    for p in b.metadata_model.parameters():  # a whole tower, embeddings included: its chain never starts
+        p.requires_grad_(False)
+    la, lb = a(**_inputs(blob)).loss, b(**_inputs(blob)).loss
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k in pa:
+        if not pb[k].requires_grad or pa[k].grad is None:  # (the audio front end is not on this case's path)
+            assert pb[k].grad is None, k
+        elif "tok_embeddings" in k:
+            torch.testing.assert_close(pa[k].grad, pb[k].grad, rtol=1e-5, atol=1e-6)
+        elif k.startswith("beatmap_model") or k == "beatmap_projection.weight":
+            assert torch.equal(pa[k].grad, pb[k].grad), k
+    # frozen embeddings + frozen bottom layer: the layers above still train, nothing reaches the embedding table
+    c = _build(name)
+    encc = c.beatmap_model.encoder
+    for p in list(encc.embeddings.parameters()) + list(encc.layers[0].parameters()):
+        p.requires_grad_(False)
+    lc = c(**_inputs(blob)).loss
+    lc.backward()
+    assert torch.equal(la, lc)
+    pc = dict(c.named_parameters())
+    for k in pa:
+        if k.startswith("beatmap_model.encoder.layers.") and not k.startswith("beatmap_model.encoder.layers.0.") and pa[k].grad is not None:
+            assert torch.equal(pa[k].grad, pc[k].grad), k
+    assert encc.embeddings.tok_embeddings.weight.grad is None and encc.layers[0].attn.Wo.weight.grad is None
+
+
 @pytest.mark.parametrize("unpad", [False, True])
 def test_output_hidden_states_match_the_reference_per_layer(unpad):
     """output_hidden_states=True: L+1 tensors - the embedding output and every layer's output (TF:...modeling_modernbert.py:457-470) -
