@@ -38,6 +38,10 @@ WORKLOADS = {
     "c2": dict(B=32, S=4096, L=256, audio_T=None, desc="default CM3P config, beatmap seq=4096, metadata seq=256, batch 32/GPU"),
     "c4": dict(B=16, S=8192, L=256, audio_T=None, desc="default CM3P config, beatmap seq=8192, metadata seq=256, batch 16/GPU"),
     "c5": dict(B=32, S=4096, L=256, audio_T=1600, desc="default CM3P config + audio-fused path (1600 mel frames), batch 32/GPU"),
+    # not a BASELINE config: SURVEY.md section 8(f) rank 2, the published v7 recipe's step (ref:configs/train/v7.yaml:25-33) =
+    # C2 shapes + CLS pooling + the MLM head on the beatmap tower with loss += 0.5 * masked-LM loss (15 % of positions labelled)
+    "v7": dict(B=32, S=4096, L=256, audio_T=None, mlm=True, desc="C2 shapes with the v7 recipe: cls_embed pooling + MLM head (has_decoder_head, "
+               "loss_type ForMaskedLM, masked_lm_prob 0.15), batch 32/GPU"),
 }
 
 
@@ -58,6 +62,9 @@ def step_flops(config, w) -> float:
     if w["audio_T"]:
         T2 = w["audio_T"] // 2
         f += tower_flops_fwd(config.beatmap_config.audio_config, B * T2, T2)
+    if w.get("mlm"):  # CM3PPredictionHead dense (H x H) + decoder (H x vocab) on every position
+        bc = config.beatmap_config
+        f += 2.0 * B * S * bc.hidden_size * (bc.hidden_size + bc.vocab_size)
     return 3.0 * f  # backward = 2 x forward, no recompute credit
 
 
@@ -75,6 +82,11 @@ def make_batch(config, w, rank: int, device):
         batch["attention_mask"] = valid.to(batch["attention_mask"].dtype)
         batch["input_ids"] = batch["input_ids"] * valid.to(batch["input_ids"].dtype)
         w["valid_token_fraction"] = float(lens.sum()) / (w["B"] * S)
+    if w.get("mlm"):
+        # ref:configs/train/v7.yaml:31-33 (labels "masked_lm", masked_lm_prob 0.15): labelled positions carry the token id, the rest -100
+        g = torch.Generator().manual_seed(987 + rank)
+        pick = (torch.rand(w["B"], w["S"], generator=g) < 0.15).to(device)
+        batch["labels"] = torch.where(pick & (batch["attention_mask"] != 0), batch["input_ids"], torch.full_like(batch["input_ids"], -100))
     return batch
 
 
@@ -211,7 +223,11 @@ def main():
     if args.batch:
         w["B"] = args.batch
         w["desc"] += f" [batch overridden to {args.batch}/GPU]"
-    config = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))  # ref:configs/model/default.yaml
+    if w.get("mlm"):
+        config = CM3PConfig(beatmap_config=dict(cls_embed=True), metadata_config=dict(cls_embed=True), has_decoder_head=True,
+                            loss_type="ForMaskedLM")  # ref:configs/train/v7.yaml:25-33
+    else:
+        config = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))  # ref:configs/model/default.yaml
     torch.manual_seed(0)
     model = CM3PModel(config).to(device).train()  # random init of the named architecture, fp32 master weights
     if not w["audio_T"]:
@@ -302,7 +318,7 @@ def main():
             result["kernel_breakdown_ms_per_step"] = {
                 k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not w.get("mlm"):  # (the oracle's timed leg covers the BASELINE workloads)
             result["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(result), flush=True)
     if world > 1:

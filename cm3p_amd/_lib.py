@@ -13,8 +13,8 @@ from ctypes import c_float, c_int, c_int64, c_void_p
 import torch
 
 F32, BF16 = 0, 1
-EPI_BF16, EPI_F32, EPI_F32_RESID = 0, 1, 2
-ABI_VERSION = 5
+EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
+ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -57,6 +57,9 @@ SIGNATURES = {
     "cm3p_cross_entropy": [_P, _I, _I, _L, _L, _P, _P, _F, _P, _P, _P],
     "cm3p_cross_entropy_masked": [_P, _L, _I, _L, _P, _L, _F, _P, _P, _P, _P],
     "cm3p_inv_valid_count": [_P, _L, _L, _P, _P],
+    "cm3p_ce_masked_stats": [_P, _L, _I, _L, _P, _L, _P, _P, _P],
+    "cm3p_ce_masked_dlogits_blocks": [_L],
+    "cm3p_ce_masked_dlogits_bf16": [_P, _L, _I, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P],
     "cm3p_add_bias_f32": [_P, _P, _L, _I, _P],
     "cm3p_colsum_blocks": [_L],
     "cm3p_colsum_f32": [_P, _P, _P, _L, _I, _P],

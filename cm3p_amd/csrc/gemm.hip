@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* A, co
             } else {
                 float* C = static_cast<float*>(Cv) + (int64_t)blockIdx.z * c_split_stride;
                 if constexpr (EPI == CM3P_EPI_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + m * ldc + n);
+                if constexpr (EPI == CM3P_EPI_F32_BIAS) v += *reinterpret_cast<const f32x4*>(R + n);
                 *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
             }
         }
@@ -236,6 +237,12 @@ int launch(const void* A, const void* B, void* C, const float* R, int64_t M, int
         case CM3P_EPI_BF16_ROPE:
             if constexpr (A_KC && B_KC) {
                 gemm_bf16_kernel<true, true, CM3P_EPI_BF16_ROPE><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        case CM3P_EPI_F32_BIAS:
+            if constexpr (A_KC && B_KC) {
+                gemm_bf16_kernel<true, true, CM3P_EPI_F32_BIAS><<<grid, 256, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, kchunk, c_split_stride, rope, bt);
                 break;
             }
             return CM3P_ERR_INVALID;
@@ -296,13 +303,13 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream) {
     CM3P_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
-    CM3P_REQUIRE(epilogue >= CM3P_EPI_BF16 && epilogue <= CM3P_EPI_F32_RESID);
+    CM3P_REQUIRE((epilogue >= CM3P_EPI_BF16 && epilogue <= CM3P_EPI_F32_RESID) || (epilogue == CM3P_EPI_F32_BIAS && a_kc && b_kc));
     CM3P_REQUIRE(cm3p_aligned16(A) && cm3p_aligned16(B) && cm3p_aligned16(C));
     CM3P_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && N % 4 == 0);
     CM3P_REQUIRE(a_kc ? (K % 8 == 0 && lda >= K) : (M % 8 == 0 && lda >= M));
     CM3P_REQUIRE(b_kc ? (K % 8 == 0 && ldb >= K) : (N % 8 == 0 && ldb >= N));
     CM3P_REQUIRE(ldc >= N && (epilogue != CM3P_EPI_BF16 || ldc % 8 == 0 || ldc % 4 == 0));
-    CM3P_REQUIRE(epilogue != CM3P_EPI_F32_RESID || (R && cm3p_aligned16(R)));
+    CM3P_REQUIRE((epilogue != CM3P_EPI_F32_RESID && epilogue != CM3P_EPI_F32_BIAS) || (R && cm3p_aligned16(R)));
     CM3P_REQUIRE(split_k >= 1 && (split_k == 1 || (epilogue == CM3P_EPI_F32 && workspace && cm3p_aligned16(workspace) && ldc == N)));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t kchunk = K;

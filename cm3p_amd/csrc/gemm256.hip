@@ -266,6 +266,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                         rres[u] = (m < M && n < N) ? *reinterpret_cast<const f32x4*>(R + m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
+                if constexpr (EPI == CM3P_EPI_F32_BIAS) {  // a thread keeps its four columns in every pass: one read per tile
+                    if (pass == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t n = n0 + ((tid + 512 * u) & 63) * 4;
+                            rres[u] = n < N ? *reinterpret_cast<const f32x4*>(R + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
             };
             load_resid(0);
 #pragma unroll
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                     const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
                     if (m < M && n < N) {
                         f32x4 a = *reinterpret_cast<const f32x4*>(ebuf + r * kRow + ch * 16);
-                        if constexpr (EPI == CM3P_EPI_F32_RESID) a += rcur[u];
+                        if constexpr (EPI == CM3P_EPI_F32_RESID || EPI == CM3P_EPI_F32_BIAS) a += rcur[u];
                         *reinterpret_cast<f32x4*>(C + m * ldc + n) = a;
                     }
                 }
@@ -340,6 +349,12 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
         case CM3P_EPI_BF16_ROPE:
             if constexpr (A_KC && B_KC) {
                 CM3P_G256(CM3P_EPI_BF16_ROPE)
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        case CM3P_EPI_F32_BIAS:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G256(CM3P_EPI_F32_BIAS)
                 break;
             }
             return CM3P_ERR_INVALID;

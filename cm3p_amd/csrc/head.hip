@@ -125,13 +125,125 @@ __global__ __launch_bounds__(256) void cross_entropy_masked_kernel(const float* 
     }
 }
 
-// inv_count[0] = 1 / max(#targets != ignore_index, 1)   (the "mean" reduction's denominator)
-__global__ __launch_bounds__(256) void inv_valid_count_kernel(const int64_t* __restrict__ target, int64_t n, int64_t ignore_index,
-                                                              float* __restrict__ inv_count) {
+// Masked-LM loss in two kernels that never materialise an fp32 gradient of the logits (1.66 GB at the C2 token count):
+//   stats:   per labelled row, loss = lse - x[target] and lse; ignored rows cost nothing (no read of their logits).
+//   dlogits: dl[r, c] = bf16(s * (exp(x[r, c] - lse[r]) - [c == target[r]])) for labelled rows, zero elsewhere and in the pad
+//            columns, s = scale_a[0] * scale_b[0] (the incoming loss gradient times 1 / #labelled, both device scalars), written
+//            in the bf16 layout the decoder's dgrad / wgrad GEMMs read; partial[blk, c] = the workgroup's column sums of the
+//            unrounded values (the decoder bias gradient), reduced afterwards in a fixed order.
+__global__ __launch_bounds__(256) void ce_masked_stats_kernel(const float* __restrict__ logits, int cols, int64_t row_stride,
+                                                              const int64_t* __restrict__ target, int64_t ignore_index,
+                                                              float* __restrict__ loss_rows, float* __restrict__ lse_rows) {
     __shared__ float red[4];
-    float c = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) c += target[i] != ignore_index ? 1.f : 0.f;
-    c = block_reduce(c, red, false);
+    const int r = blockIdx.x;
+    const int64_t t = target[r];
+    if (t == ignore_index) {  // block-uniform
+        if (threadIdx.x == 0) {
+            loss_rows[r] = 0.f;
+            lse_rows[r] = 0.f;
+        }
+        return;
+    }
+    const float* x = logits + (int64_t)r * row_stride;
+    float mx = -__builtin_huge_valf();
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, x[c]);
+    mx = block_reduce(mx, red, true);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) se += expf(x[c] - mx);
+    se = block_reduce(se, red, false);
+    const float lse = mx + logf(se);
+    if (threadIdx.x == 0) {
+        loss_rows[r] = lse - x[t];
+        lse_rows[r] = lse;
+    }
+}
+
+constexpr int kDlRows = 64;   // rows per workgroup
+constexpr int kDlQuads = 4;   // 4-column groups per thread: covers pitch <= 4 * 256 * 4 = 4096 columns
+
+__global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __restrict__ logits, int cols, int64_t pitch, int64_t rows,
+                                                                const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                const float* __restrict__ lse_rows, const float* __restrict__ scale_a,
+                                                                const float* __restrict__ scale_b, uint16_t* __restrict__ dl,
+                                                                float* __restrict__ partial) {
+    const float s = scale_a[0] * scale_b[0];
+    const int quads = (int)(pitch / 4);
+    f32x4 acc[kDlQuads];
+#pragma unroll
+    for (int q = 0; q < kDlQuads; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t r0 = (int64_t)blockIdx.x * kDlRows;
+    const int64_t r1 = r0 + kDlRows < rows ? r0 + kDlRows : rows;
+    // the row loop is serial: fetch its 64 targets and lse values in one go instead of one dependent load per row
+    __shared__ int64_t tg[kDlRows];
+    __shared__ float ls[kDlRows];
+    if (threadIdx.x < kDlRows && r0 + threadIdx.x < rows) {
+        tg[threadIdx.x] = target[r0 + threadIdx.x];
+        ls[threadIdx.x] = lse_rows[r0 + threadIdx.x];
+    }
+    __syncthreads();
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t t = tg[r - r0];  // workgroup-uniform
+        uint16_t* drow = dl + r * pitch;
+        if (t == ignore_index) {
+#pragma unroll
+            for (int q = 0; q < kDlQuads; ++q) {
+                const int c4 = threadIdx.x + 256 * q;
+                if (c4 < quads) *reinterpret_cast<uint2*>(drow + 4 * c4) = uint2{0u, 0u};
+            }
+            continue;
+        }
+        const float* x = logits + r * pitch;
+        const float lse = ls[r - r0];
+#pragma unroll
+        for (int q = 0; q < kDlQuads; ++q) {
+            const int c4 = threadIdx.x + 256 * q;
+            if (c4 < quads) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * c4);
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * c4 + j;
+                    g[j] = c < cols ? s * (expf(v[j] - lse) - (c == t ? 1.0f : 0.0f)) : 0.f;
+                }
+                acc[q] += g;
+                *reinterpret_cast<uint2*>(drow + 4 * c4) = uint2{pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kDlQuads; ++q) {
+        const int c4 = threadIdx.x + 256 * q;
+        if (c4 < quads) *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * pitch + 4 * c4) = acc[q];
+    }
+}
+
+// One 1024-thread workgroup, fixed summation order: thread t takes elements t, t + 1024, ... in four interleaved partial sums
+// (four loads in flight per thread - a single load per iteration made these latency-bound: 0.2 ms for 128 K elements).
+__device__ __forceinline__ float block_reduce16(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < 16; ++w) r += red[w];
+    return r;  // valid in thread 0
+}
+
+// inv_count[0] = 1 / max(#targets != ignore_index, 1)   (the "mean" reduction's denominator)
+__global__ __launch_bounds__(1024) void inv_valid_count_kernel(const int64_t* __restrict__ target, int64_t n, int64_t ignore_index,
+                                                               float* __restrict__ inv_count) {
+    __shared__ float red[16];
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int64_t i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) {
+        const int64_t t0 = target[i], t1 = target[i + 1024], t2 = target[i + 2048], t3 = target[i + 3072];
+        c0 += t0 != ignore_index;
+        c1 += t1 != ignore_index;
+        c2 += t2 != ignore_index;
+        c3 += t3 != ignore_index;
+    }
+    for (; i < n; i += 1024) c0 += target[i] != ignore_index;
+    const float c = block_reduce16((float)((c0 + c1) + (c2 + c3)), red);  // counts: exact in fp32 up to 2^24 per workgroup lane sum
     if (threadIdx.x == 0) inv_count[0] = 1.0f / fmaxf(c, 1.0f);
 }
 
@@ -157,12 +269,64 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
         partial[(int64_t)blockIdx.x * cols + c] = acc;
     }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * cols + c];
-    out[c] = s;
+// four columns per thread, two rows in flight (cols % 4 == 0, cols <= 4096); same fixed per-column order of additions as above
+__global__ __launch_bounds__(256) void colsum_rows_vec_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t rows, int cols) {
+    constexpr int MAXQ = 4;
+    const int quads = cols / 4;
+    f32x4 acc[MAXQ];
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t step = gridDim.x;
+    int64_t r = blockIdx.x;
+    for (; r + step < rows; r += 2 * step) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int qd = threadIdx.x + 256 * k;
+            if (qd < quads) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * cols + 4 * qd);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(x + (r + step) * cols + 4 * qd);
+                acc[k] += a;
+                acc[k] += b;
+            }
+        }
+    }
+    for (; r < rows; r += step) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int qd = threadIdx.x + 256 * k;
+            if (qd < quads) acc[k] += *reinterpret_cast<const f32x4*>(x + r * cols + 4 * qd);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int qd = threadIdx.x + 256 * k;
+        if (qd < quads) *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * cols + 4 * qd) = acc[k];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    // 64 columns per workgroup; wave g sums blocks [g*per, (g+1)*per) with four loads in flight, then the four waves' sums are
+    // added in a fixed order (a single thread walking all nblk partials was latency-bound: 0.6 ms for 2048 partials)
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int per = (nblk + 3) / 4;
+    const int b0 = g * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < C) {
+        int b = b0;
+        for (; b + 3 < b1; b += 4) {
+            const float v0 = partial[(int64_t)b * C + col], v1 = partial[(int64_t)(b + 1) * C + col];
+            const float v2 = partial[(int64_t)(b + 2) * C + col], v3 = partial[(int64_t)(b + 3) * C + col];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; b < b1; ++b) s0 += partial[(int64_t)b * C + col];
+    }
+    red[g][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && col < C) out[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 __global__ void first_zero_index_kernel(const int64_t* __restrict__ classes, int B, int V, int64_t* __restrict__ idx) {
@@ -202,12 +366,20 @@ __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, c
 }
 
 // out[0] = scale * sum_i x[i]
-__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale,
-                                                  int accumulate) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
-    s = block_reduce(s, red, false);
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float scale,
+                                                   int accumulate) {
+    __shared__ float red[16];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) {
+        const float a = x[i], b = x[i + 1024], c = x[i + 2048], d = x[i + 3072];
+        s0 += a;
+        s1 += b;
+        s2 += c;
+        s3 += d;
+    }
+    for (; i < n; i += 1024) s0 += x[i];
+    const float s = block_reduce16((s0 + s1) + (s2 + s3), red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + scale * s : scale * s;
 }
 
@@ -291,9 +463,36 @@ int cm3p_cross_entropy_masked(const float* logits, int64_t rows, int cols, int64
     return CM3P_OK;
 }
 
+int cm3p_ce_masked_stats(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target, int64_t ignore_index,
+                         float* loss_rows, float* lse_rows, void* stream) {
+    CM3P_REQUIRE(logits && target && loss_rows && lse_rows && rows > 0 && cols > 0 && row_stride >= cols);
+    ce_masked_stats_kernel<<<(unsigned)rows, 256, 0, static_cast<hipStream_t>(stream)>>>(logits, cols, row_stride, target, ignore_index,
+                                                                                        loss_rows, lse_rows);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_ce_masked_dlogits_blocks(int64_t rows) { return (int)((rows + kDlRows - 1) / kDlRows); }
+
+int cm3p_ce_masked_dlogits_bf16(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target, int64_t ignore_index,
+                                const float* lse_rows, const float* scale_a, const float* scale_b, void* dlogits_bf16, float* partial,
+                                float* colsum, void* stream) {
+    CM3P_REQUIRE(logits && target && lse_rows && scale_a && scale_b && dlogits_bf16 && partial && colsum && rows > 0 && cols > 0);
+    CM3P_REQUIRE(row_stride >= cols && row_stride % 4 == 0 && row_stride <= 4 * 256 * kDlQuads && cm3p_aligned16(logits) &&
+                 cm3p_aligned16(partial) && (reinterpret_cast<uintptr_t>(dlogits_bf16) & 7) == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = cm3p_ce_masked_dlogits_blocks(rows);
+    ce_masked_dlogits_kernel<<<nblk, 256, 0, s>>>(logits, cols, row_stride, rows, target, ignore_index, lse_rows, scale_a, scale_b,
+                                                  (uint16_t*)dlogits_bf16, partial);
+    CM3P_LAUNCH_CHECK();
+    colsum_final_kernel<<<(int)((row_stride + 63) / 64), 256, 0, s>>>(partial, colsum, nblk, (int)row_stride);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
 int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index, float* inv_count, void* stream) {
     CM3P_REQUIRE(target && inv_count && n > 0);
-    inv_valid_count_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(target, n, ignore_index, inv_count);
+    inv_valid_count_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(target, n, ignore_index, inv_count);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -320,9 +519,10 @@ int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, in
     CM3P_REQUIRE(x && partial && out && rows > 0 && cols > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nblk = cm3p_colsum_blocks(rows);
-    colsum_rows_kernel<<<nblk, 256, 0, s>>>(x, partial, rows, cols);
+    if (cols % 4 == 0 && cols <= 4096 && cm3p_aligned16(x) && cm3p_aligned16(partial)) colsum_rows_vec_kernel<<<nblk, 256, 0, s>>>(x, partial, rows, cols);
+    else colsum_rows_kernel<<<nblk, 256, 0, s>>>(x, partial, rows, cols);
     CM3P_LAUNCH_CHECK();
-    colsum_final_kernel<<<(cols + 255) / 256, 256, 0, s>>>(partial, out, nblk, cols);
+    colsum_final_kernel<<<(cols + 63) / 64, 256, 0, s>>>(partial, out, nblk, cols);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -361,7 +561,7 @@ int cm3p_dot_f32(const float* a, const float* b, float* out, int64_t n, void* st
 
 int cm3p_sum_f32(const float* x, float* out, int64_t n, float scale, int accumulate, void* stream) {
     CM3P_REQUIRE(x && out && n > 0);
-    sum_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(x, out, n, scale, accumulate);
+    sum_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(x, out, n, scale, accumulate);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

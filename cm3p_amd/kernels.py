@@ -337,6 +337,26 @@ def cross_entropy_masked(logits: Tensor, cols: int, target: Tensor, ignore_index
     return loss_rows, dlogits
 
 
+def ce_masked_stats(logits: Tensor, cols: int, target: Tensor, ignore_index: int):
+    """-> (loss_rows, lse_rows), zero for ignored rows."""
+    rows, pitch = logits.shape
+    loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    lse_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    call("cm3p_ce_masked_stats", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, ptr(loss_rows), ptr(lse_rows), stream())
+    return loss_rows, lse_rows
+
+
+def ce_masked_dlogits_bf16(logits: Tensor, cols: int, target: Tensor, ignore_index: int, lse_rows: Tensor, scale_a: Tensor, scale_b: Tensor):
+    """-> (dlogits bf16 [rows, pitch], column sums fp32 [pitch]) of scale_a * scale_b * (softmax - onehot) on the labelled rows."""
+    rows, pitch = logits.shape
+    dl = torch.empty((rows, pitch), dtype=torch.bfloat16, device=logits.device)
+    part = torch.empty((query("cm3p_ce_masked_dlogits_blocks", rows), pitch), dtype=torch.float32, device=logits.device)
+    colsum = torch.empty((pitch,), dtype=torch.float32, device=logits.device)
+    call("cm3p_ce_masked_dlogits_bf16", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, ptr(lse_rows), ptr(scale_a), ptr(scale_b),
+         ptr(dl), ptr(part), ptr(colsum), stream())
+    return dl, colsum
+
+
 def inv_valid_count(target: Tensor, ignore_index: int) -> Tensor:
     out = torch.empty((1,), dtype=torch.float32, device=target.device)
     call("cm3p_inv_valid_count", ptr(target), target.numel(), ignore_index, ptr(out), stream())

@@ -198,79 +198,115 @@ def cm3p_loss_hip(logits_per_metadata: Tensor, metadata_variation_classes: Optio
     return _CrossEntropySumFn.apply(specs, L)
 
 
+def _mlm_head_forward(h: Tensor, Wd: Tensor, bd: Optional[Tensor], norm_w: Tensor, Wdec: Tensor, bdec: Optional[Tensor], eps: float):
+    """decoder(norm(gelu(dense(h)))) (CM3PPredictionHead + decoder, ref:cm3p/modeling_cm3p.py:991,1229-1238) -> (fp32 logits
+    [T, Vp], what the backward needs, parameter dtypes); Vp = vocab rounded up to a multiple of 64, so that the decoder's input-
+    gradient GEMM, which contracts over Vp, runs on the 256 x 256 kernel (pad columns hold the zero pad weights' product;
+    callers slice)."""
+    from ._lib import EPI_F32, EPI_F32_BIAS
+    from .encoder import _bf16_weight
+
+    T, H = h.shape
+    V = Wdec.shape[0]
+    Vp = (V + 63) // 64 * 64
+    hb = K.cast_bf16(h.detach().contiguous())
+    Wd_b = _bf16_weight(Wd)
+    Wdec_b = _bf16_weight(Wdec)
+    if Vp != V:
+        pad = torch.zeros((Vp, H), dtype=torch.bfloat16, device=h.device)
+        pad[:V].copy_(Wdec_b)  # layout only: pad the vocabulary to the GEMM's column granularity
+        Wdec_b = pad
+    bd32 = _f32(bd.detach()).contiguous() if bd is not None else torch.zeros((H,), dtype=torch.float32, device=h.device)
+    w32 = _f32(norm_w.detach()).contiguous()
+    z = K.gemm(hb, Wd_b, T, H, H, True, True, EPI_F32)
+    _, a32 = K.bias_gelu_fwd(z, bd32, False, True)
+    _, y, mean, rstd = K.layernorm_fwd(a32, w32, eps, False, True)
+    if bdec is not None:  # the decoder bias is added while the GEMM stores its tiles (no extra pass over [T, Vp])
+        bp = torch.zeros((Vp,), dtype=torch.float32, device=h.device)
+        bp[:V].copy_(_f32(bdec.detach()))
+        logits = K.gemm(y, Wdec_b, T, Vp, H, True, True, EPI_F32_BIAS, resid=bp)
+    else:
+        logits = K.gemm(y, Wdec_b, T, Vp, H, True, True, EPI_F32)
+    pack = (hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V)
+    meta = (Wd.dtype, bd.dtype if bd is not None else None, norm_w.dtype, Wdec.dtype, bdec.dtype if bdec is not None else None)
+    return logits, pack, meta
+
+
+def _mlm_head_backward(pack, meta, need_dh: bool, dlb: Tensor, dbdec_full: Optional[Tensor]):
+    """dlb: bf16 [T, Vp] gradient of the padded logits; dbdec_full: its fp32 column sums.  -> gradients of
+    (h, Wd, bd, norm_w, Wdec, bdec)."""
+    from ._lib import EPI_F32
+
+    hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V = pack
+    dWd_t, dbd_t, dnw_t, dWdec_t, dbdec_t = meta
+    T, H = hb.shape
+    dy = K.linear_dgrad(dlb, Wdec_b)
+    dWdec = K.linear_wgrad(dlb, y)[:V]
+    dbdec = dbdec_full[:V] if dbdec_t is not None else None
+    da, _, dnw = K.layernorm_bwd(dy, a32, w32, mean, rstd, None, False, inplace=False)
+    dz, dbd = K.bias_gelu_bwd(da, z, bd32)
+    dh = K.gemm(dz, Wd_b, T, H, H, True, False, EPI_F32) if need_dh else None
+    dWd = K.linear_wgrad(dz, hb)
+    return (dh, dWd.to(dWd_t), dbd.to(dbd_t) if dbd_t is not None else None, dnw.to(dnw_t), dWdec.to(dWdec_t),
+            dbdec.to(dbdec_t) if dbdec is not None else None)
+
+
 class _MLMHeadFn(torch.autograd.Function):
-    """decoder(norm(gelu(dense(h)))) (CM3PPredictionHead + decoder, ref:cm3p/modeling_cm3p.py:991,1229-1238) -> fp32
-    logits [T, Vp], Vp = vocab rounded up to a multiple of 8 (pad columns hold the zero pad weights' product; callers slice)."""
+    """The MLM head alone (logits wanted, no labels): see _mlm_head_forward."""
 
     @staticmethod
     def forward(ctx, h: Tensor, Wd: Tensor, bd: Optional[Tensor], norm_w: Tensor, Wdec: Tensor, bdec: Optional[Tensor], eps: float):
-        from ._lib import EPI_F32
-        from .encoder import _bf16_weight
-
-        T, H = h.shape
-        V = Wdec.shape[0]
-        Vp = (V + 7) // 8 * 8
-        hb = K.cast_bf16(h.detach().contiguous())
-        Wd_b = _bf16_weight(Wd)
-        Wdec_b = _bf16_weight(Wdec)
-        if Vp != V:
-            pad = torch.zeros((Vp, H), dtype=torch.bfloat16, device=h.device)
-            pad[:V].copy_(Wdec_b)  # layout only: pad the vocabulary to the GEMM's column granularity
-            Wdec_b = pad
-        bd32 = _f32(bd.detach()).contiguous() if bd is not None else torch.zeros((H,), dtype=torch.float32, device=h.device)
-        w32 = _f32(norm_w.detach()).contiguous()
-        z = K.gemm(hb, Wd_b, T, H, H, True, True, EPI_F32)
-        _, a32 = K.bias_gelu_fwd(z, bd32, False, True)
-        _, y, mean, rstd = K.layernorm_fwd(a32, w32, eps, False, True)
-        logits = K.gemm(y, Wdec_b, T, Vp, H, True, True, EPI_F32)
-        if bdec is not None:
-            bp = torch.zeros((Vp,), dtype=torch.float32, device=h.device)
-            bp[:V].copy_(_f32(bdec.detach()))
-            K.add_bias_(logits, bp)
-        ctx.pack = (hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V)
-        ctx.meta = (Wd.dtype, bd.dtype if bd is not None else None, norm_w.dtype, Wdec.dtype, bdec.dtype if bdec is not None else None)
+        logits, ctx.pack, ctx.meta = _mlm_head_forward(h, Wd, bd, norm_w, Wdec, bdec, eps)
         return logits
 
     @staticmethod
     def backward(ctx, dl: Tensor):
-        from ._lib import EPI_F32
-
-        hb, Wd_b, Wdec_b, bd32, w32, z, a32, y, mean, rstd, V = ctx.pack
-        dWd_t, dbd_t, dnw_t, dWdec_t, dbdec_t = ctx.meta
         dl = dl.contiguous()
-        T, H = hb.shape
-        dlb = K.cast_bf16(dl)
-        dy = K.linear_dgrad(dlb, Wdec_b)
-        dWdec = K.linear_wgrad(dlb, y)[:V]
-        dbdec = K.colsum_f32(dl)[:V] if dbdec_t is not None else None
-        da, _, dnw = K.layernorm_bwd(dy, a32, w32, mean, rstd, None, False, inplace=False)
-        dz, dbd = K.bias_gelu_bwd(da, z, bd32)
-        dh = K.gemm(dz, Wd_b, T, H, H, True, False, EPI_F32) if ctx.needs_input_grad[0] else None
-        dWd = K.linear_wgrad(dz, hb)
-        return (dh, dWd.to(dWd_t), dbd.to(dbd_t) if dbd_t is not None else None, dnw.to(dnw_t), dWdec.to(dWdec_t),
-                dbdec.to(dbdec_t) if dbdec is not None else None, None)
+        dbdec_full = K.colsum_f32(dl) if ctx.meta[4] is not None else None
+        return (*_mlm_head_backward(ctx.pack, ctx.meta, ctx.needs_input_grad[0], K.cast_bf16(dl), dbdec_full), None)
 
 
-class _MaskedLMLossFn(torch.autograd.Function):
-    """ForMaskedLMLoss (TF:loss/loss_utils.py:32-46,74-91): mean cross entropy over labels != -100, or the sum divided by
-    `num_items_in_batch` when the Trainer supplies it.  logits: fp32 [T, Vp] with `vocab` live columns."""
+class _MLMHeadLossFn(torch.autograd.Function):
+    """MLM head + ForMaskedLMLoss in one node (ref:cm3p/modeling_cm3p.py:987-996; TF:loss/loss_utils.py:32-46,74-91: mean cross
+    entropy over labels != -100, or the sum divided by `num_items_in_batch` when the Trainer supplies it) -> (fp32 logits
+    [T, Vp], loss).  Keeping both in one node lets the backward write the logits' gradient once, in bf16, straight into the
+    layout the decoder's dgrad / wgrad GEMMs read, together with the decoder-bias gradient: no [T, Vp] fp32 gradient tensor,
+    no scale / cast / column-sum passes over it, and the 85 % of rows without a label are never read."""
 
     @staticmethod
-    def forward(ctx, logits: Tensor, labels: Tensor, vocab: int, num_items: Optional[Tensor]):
+    def forward(ctx, h: Tensor, Wd: Tensor, bd: Optional[Tensor], norm_w: Tensor, Wdec: Tensor, bdec: Optional[Tensor], eps: float,
+                labels: Tensor, num_items: Optional[Tensor]):
+        logits, ctx.pack, ctx.meta = _mlm_head_forward(h, Wd, bd, norm_w, Wdec, bdec, eps)
+        V = Wdec.shape[0]
         lab = labels.reshape(-1).contiguous().to(torch.int64)
         if num_items is None:
             inv = K.inv_valid_count(lab, -100)
         else:
             n = num_items if torch.is_tensor(num_items) else torch.tensor(float(num_items))
             inv = (1.0 / n.to(device=logits.device, dtype=torch.float32)).reshape(1).contiguous()  # scalar plumbing
-        lr, dlog = K.cross_entropy_masked(logits.detach().contiguous(), vocab, lab, -100, 1.0, inv, True)
-        loss = K.scale_by(K.sum_f32(lr, 1.0), inv)
-        ctx.dlog = dlog
-        return loss.reshape(())
+        loss_rows, lse_rows = K.ce_masked_stats(logits, V, lab, -100)
+        loss = K.scale_by(K.sum_f32(loss_rows, 1.0), inv)
+        ctx.ce = (logits, lab, lse_rows, inv, V)
+        ctx.set_materialize_grads(False)
+        return logits, loss.reshape(())
 
     @staticmethod
-    def backward(ctx, g: Tensor):
-        return K.scale_by(ctx.dlog, g.reshape(1).contiguous()), None, None, None
+    def backward(ctx, dl_ext: Optional[Tensor], dloss: Optional[Tensor]):
+        logits, lab, lse_rows, inv, V = ctx.ce
+        dlb = colsum = None
+        if dloss is not None:
+            dlb, colsum = K.ce_masked_dlogits_bf16(logits, V, lab, -100, lse_rows, dloss.reshape(1).contiguous().float(), inv)
+        if dl_ext is not None:  # the logits were also used outside the loss: add that gradient (not the Trainer's path)
+            dl_ext = dl_ext.contiguous().float()
+            cs = K.colsum_f32(dl_ext)
+            if dlb is None:
+                dlb, colsum = K.cast_bf16(dl_ext), cs
+            else:
+                _, dlb = K.add_f32(dl_ext, dlb, want_bf16=True, inplace=False)
+                colsum, _ = K.add_f32(colsum, cs, want_bf16=False, inplace=False)
+        if dlb is None:
+            return (None,) * 9
+        return (*_mlm_head_backward(ctx.pack, ctx.meta, ctx.needs_input_grad[0], dlb, colsum), None, None, None)
 
 
 class _AddScaledFn(torch.autograd.Function):
@@ -635,11 +671,15 @@ class CM3PModel(CM3PPreTrainedModel):
             hs = beatmap_outputs.last_hidden_state
             Bq, Sq, Hq = hs.shape
             V = self.config.beatmap_config.vocab_size
-            lp = _MLMHeadFn.apply(hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
-                                  self.decoder.weight, self.decoder.bias, self.config.beatmap_config.norm_eps)
-            logits = lp.view(Bq, Sq, -1)[..., :V]
+            head_args = (hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
+                         self.decoder.weight, self.decoder.bias, self.config.beatmap_config.norm_eps)
+            mlm = None
             if labels is not None and return_loss:
-                mlm = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))
+                lp, mlm = _MLMHeadLossFn.apply(*head_args, labels, kwargs.get("num_items_in_batch"))
+            else:
+                lp = _MLMHeadFn.apply(*head_args)
+            logits = lp.view(Bq, Sq, -1)[..., :V]
+            if mlm is not None:
                 if torch.is_tensor(loss):
                     loss = _AddScaledFn.apply(loss, mlm, 0.5)
                 else:
@@ -763,12 +803,14 @@ class CM3PForMaskedLM(CM3PPreTrainedModel):
             idx = torch.nonzero(labels != self.sparse_pred_ignore_index).flatten()
             rows = _TakeRowsFn.apply(rows, idx)
             labels = labels[idx]
-        lp = _MLMHeadFn.apply(rows, self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
-                              self.decoder.weight, self.decoder.bias, self.config.norm_eps)
-        logits = lp[..., :V] if sparse else lp.view(Bq, Sq, -1)[..., :V]
+        head_args = (rows, self.head.dense.weight, self.head.dense.bias, self.head.norm.weight, self.decoder.weight, self.decoder.bias,
+                     self.config.norm_eps)
         loss = None
         if labels is not None:
-            loss = _MaskedLMLossFn.apply(lp, labels, V, kwargs.get("num_items_in_batch"))
+            lp, loss = _MLMHeadLossFn.apply(*head_args, labels, kwargs.get("num_items_in_batch"))
+        else:
+            lp = _MLMHeadFn.apply(*head_args)
+        logits = lp[..., :V] if sparse else lp.view(Bq, Sq, -1)[..., :V]
         return MaskedLMOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=None)
 
 

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 5
+#define CM3P_ABI_VERSION 6
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -81,11 +81,14 @@ int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int3
  *   a_kc = 1: A is [M, lda] with k contiguous;   a_kc = 0: A is [K, lda] with m contiguous (element (m,k) at A[k*lda+m]).
  *   b_kc likewise for B over (n, k).
  *   epilogue: CM3P_EPI_BF16 (C bf16), CM3P_EPI_F32 (C fp32), CM3P_EPI_F32_RESID (C fp32 = R + acc; R fp32 [M, ldc], may
- *   alias C).  Constraints: contiguous extents and leading dimensions are multiples of 8 elements.
+ *   alias C), CM3P_EPI_F32_BIAS (C fp32 = acc + R[n]; R fp32 [N]: nn.Linear's bias added while the tile is stored - the
+ *   decoder of the MLM head, ref:cm3p/modeling_cm3p.py:767,991; forward orientation a_kc = b_kc = 1 only).
+ *   Constraints: contiguous extents and leading dimensions are multiples of 8 elements.
  */
 #define CM3P_EPI_BF16 0
 #define CM3P_EPI_F32 1
 #define CM3P_EPI_F32_RESID 2
+#define CM3P_EPI_F32_BIAS 5
 /* split_k > 1 (CM3P_EPI_F32 only, ldc == N): the contraction is cut into split_k ranges whose fp32 partial tiles go to
  * `workspace` (split_k * M * N floats) and are then summed in a fixed order - used for dW, whose contraction runs over
  * all tokens while its output is only a few hundred tiles. */
@@ -221,6 +224,19 @@ int cm3p_cross_entropy_masked(const float* logits, int64_t rows, int cols, int64
                               int64_t ignore_index, float grad_scale, const float* inv_count, float* loss_rows, float* dlogits,
                               void* stream);
 int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index, float* inv_count, void* stream);
+/* The training path of the same loss without an fp32 gradient of the logits ([B*S, vocab] fp32 = 1.66 GB at B=32, S=4096):
+ * cm3p_ce_masked_stats: loss_rows[r] = lse_r - x[r, target_r] and lse_rows[r] = lse_r for labelled rows, both 0 for ignored
+ *   rows (whose logits are not read).
+ * cm3p_ce_masked_dlogits_bf16: dlogits_bf16[r, c] = bf16(s * (exp(x[r, c] - lse_r) - [c == target_r])), s = scale_a[0] * scale_b[0]
+ *   (device scalars: the incoming loss gradient and 1 / #labelled), zero for ignored rows and pad columns - the operand of the
+ *   decoder's dgrad / wgrad GEMMs; colsum[c] = sum_r of the unrounded values (the decoder bias gradient, fixed order).
+ *   row_stride % 4 == 0 and <= 4096; partial: [cm3p_ce_masked_dlogits_blocks(rows), row_stride] fp32 workspace. */
+int cm3p_ce_masked_stats(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target, int64_t ignore_index,
+                         float* loss_rows, float* lse_rows, void* stream);
+int cm3p_ce_masked_dlogits_blocks(int64_t rows);
+int cm3p_ce_masked_dlogits_bf16(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target, int64_t ignore_index,
+                                const float* lse_rows, const float* scale_a, const float* scale_b, void* dlogits_bf16, float* partial,
+                                float* colsum, void* stream);
 int cm3p_add_bias_f32(float* x, const float* bias, int64_t rows, int cols, void* stream);
 int cm3p_colsum_blocks(int64_t rows);
 int cm3p_colsum_f32(const float* x, float* partial, float* out, int64_t rows, int cols, void* stream);

@@ -103,6 +103,19 @@ def test_gemm256_wgrad_layout(K, T, N, K_):
     _assert_close(got, dy.t() @ x, 0, 0, "wgrad256")
 
 
+@pytest.mark.parametrize("M,N,K_", [(8192, 3200, 768), (300, 72, 64), (16384, 776, 128)])
+def test_gemm_bias_epilogue(K, M, N, K_):
+    """CM3P_EPI_F32_BIAS: C = A B^T + bias[n] on the 256 x 256 and the 128 x 128 kernel (integer-valued operands: exact)."""
+    from cm3p_amd._lib import EPI_F32_BIAS
+
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-2, 3, (M, K_), generator=g).float()
+    b = torch.randint(-2, 3, (N, K_), generator=g).float()
+    bias = torch.randint(-50, 50, (N,), generator=g).float() / 4
+    got = K.gemm(_bf(a).to(DEV), _bf(b).to(DEV), M, N, K_, True, True, EPI_F32_BIAS, resid=bias.to(DEV))
+    _assert_close(got, a @ b.t() + bias, 0, 0, "bias epilogue")
+
+
 def test_gemm_random_tolerance(K):
     """Random normal data: bf16 inputs, fp32 accumulation; error bound 2e-3 relative to sqrt(K)."""
     g = torch.Generator().manual_seed(3)
@@ -428,6 +441,47 @@ def test_head_kernels(K):
     K.sum_f32(lc, 0.5 / 12, out=got_loss, accumulate=True)
     _assert_close(got_loss, loss.detach().reshape(1), 1e-6, 1e-6, "clip loss")
     _assert_close(d, Lr.grad, 1e-7, 1e-5, "clip dlogits")
+
+
+@pytest.mark.parametrize("rows,vocab,frac", [(300, 3167, 0.15), (70, 37, 0.5), (129, 1000, 0.0), (64, 3167, 1.0)])
+def test_masked_lm_loss_kernels(K, rows, vocab, frac):
+    """cm3p_ce_masked_stats / cm3p_ce_masked_dlogits_bf16 / cm3p_inv_valid_count / cm3p_sum_f32 against
+    F.cross_entropy(ignore_index=-100) (TF:loss/loss_utils.py:32-46): loss within fp32 summation-order error, the bf16 gradient
+    within one bf16 rounding of the fp32 gradient, its fp32 column sums tight, ignored rows and pad columns exactly zero."""
+    g = torch.Generator().manual_seed(rows + vocab)
+    pitch = (vocab + 7) // 8 * 8
+    x = torch.zeros(rows, pitch)
+    x[:, :vocab] = torch.randn(rows, vocab, generator=g) * 2
+    lab = torch.randint(0, vocab, (rows,), generator=g)
+    lab = torch.where(torch.rand(rows, generator=g) < frac, lab, torch.full_like(lab, -100))
+    if frac == 1.0:
+        lab[0] = vocab - 1  # last live column is a target
+    xr = x[:, :vocab].clone().requires_grad_(True)
+    n_valid = int((lab != -100).sum())
+    want = F.cross_entropy(xr, lab, ignore_index=-100, reduction="sum") / max(n_valid, 1)
+    up = 0.37  # incoming loss gradient
+    (want * up).backward()
+    xd, ld = x.to(DEV), lab.to(DEV)
+    inv = K.inv_valid_count(ld, -100)
+    _assert_close(inv, torch.tensor([1.0 / max(n_valid, 1)]), 0, 1e-7, "inv count")
+    loss_rows, lse_rows = K.ce_masked_stats(xd, vocab, ld, -100)
+    got = K.scale_by(K.sum_f32(loss_rows, 1.0), inv)
+    _assert_close(got, want.detach().reshape(1), 1e-6, 1e-5, "masked-LM loss")
+    assert torch.equal(loss_rows.cpu()[lab == -100], torch.zeros(rows - n_valid))
+    dl, colsum = K.ce_masked_dlogits_bf16(xd, vocab, ld, -100, lse_rows, torch.tensor([up], device=DEV), inv)
+    assert dl.dtype == torch.bfloat16 and dl.shape == (rows, pitch)
+    wantg = torch.zeros(rows, pitch)
+    wantg[:, :vocab] = xr.grad
+    _assert_close(dl, wantg, 1e-8, 2 ** -8, "masked-LM dlogits (bf16)")
+    assert torch.equal(dl.float().cpu()[lab == -100], torch.zeros(rows - n_valid, pitch))
+    assert torch.equal(dl.float().cpu()[:, vocab:], torch.zeros(rows, pitch - vocab))
+    _assert_close(colsum, wantg.sum(0), 1e-6, 1e-4, "decoder bias gradient")
+    # the 1024-thread reductions at a length that exercises the unrolled body, the tail and every wave
+    v = torch.randn(131072 + 777, generator=g)
+    _assert_close(K.sum_f32(v.to(DEV), 0.5), (0.5 * v.double().sum()).float().reshape(1), 2e-3, 1e-5, "sum_f32 long")
+    t = torch.randint(0, 5, (131072 + 777,), generator=g)
+    t = torch.where(t == 0, torch.full_like(t, -100), t)
+    _assert_close(K.inv_valid_count(t.to(DEV), -100), torch.tensor([1.0 / int((t != -100).sum())]), 0, 1e-7, "inv count long")
 
 
 # ------------------------------------------------------------------------------------------------ audio front end

@@ -438,6 +438,33 @@ def test_sparse_prediction_mlm_matches_reference_fixture():
     assert _rel(ml.beatmap_model.encoder.layers[0].mlp.Wi.weight.grad, gold["mlm_sparse.grad.beatmap_model.encoder.layers.0.mlp.Wi.weight"]) <= 6e-2
 
 
+def test_mlm_logits_used_outside_the_loss_still_get_their_gradient():
+    """The MLM head and its loss are one autograd node that writes the logits' gradient in bf16 for the decoder GEMMs; a
+    gradient that arrives through the returned `logits` as well (not the Trainer's path) is added to it.  Checked against the
+    sum of the two separate backward passes."""
+    name = "d64_mlm"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    ins = _inputs(blob)
+    w = torch.randn(tuple(blob["logits"].shape), generator=torch.Generator().manual_seed(3)).to(DEV) * 1e-3
+
+    def grads(use_loss, use_logits):
+        m = _build(name)
+        out = m(**ins)
+        obj = 0.0
+        if use_loss:
+            obj = obj + out.loss
+        if use_logits:
+            obj = obj + (out.logits * w).sum()
+        obj.backward()
+        return {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+    both, a, b = grads(True, True), grads(True, False), grads(False, True)
+    assert set(both) == set(a)
+    for k in both:
+        want = a[k] + (b[k] if k in b else 0)
+        assert _rel(both[k], want) <= 2e-2, (k, _rel(both[k], want))
+
+
 def test_gradient_checkpointing_recomputes_bit_identically():
     """model.gradient_checkpointing_enable() (ref:cm3p/modeling_cm3p.py:257 supports_gradient_checkpointing): the stack keeps one
     tensor per layer and recomputes the rest with the same deterministic kernels - losses and gradients are bit-identical."""
