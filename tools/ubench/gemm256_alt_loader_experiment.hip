@@ -1,0 +1,505 @@
+// NOT BUILT - late-r01 experiment.  gemm256.hip with -DCM3P_ALT_LOADER: the two wave groups of the workgroup take
+// turns streaming the whole next k-tile (16 LDS-DMA instructions per loader wave, scalar-base addressing: one VGPR offset per
+// lane instead of pointer tables) while their SIMD partners go straight to the MFMAs.  Passes the GEMM parity tests; timing
+// within +-5 % of the shipped kernel in a one-call A/B (forward -5 %, dgrad +2 %, wgrad +-2 %): neither which wave issues the
+// DMA nor when in the k-step it is issued is the limiter.  175-240 VGPRs (no pointer tables) but 60-90 spilled SGPRs.
+// Large-tile bf16 MFMA GEMM: 256 x 256 x 64 per 512-thread workgroup, operands streamed global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR staging, no ds_write), double-buffered, one barrier per k-step.
+//
+// Same contract as gemm.hip (C[m,n] = sum_k A(m,k) B(n,k) (+R); a_kc / b_kc layouts; epilogues; split-K) for the
+// shapes that dominate the step: K a multiple of 64.  The 128 x 128 kernel in gemm.hip keeps every other shape.
+// Why a second kernel: at 128 x 128 a workgroup moves 1/64 byte per flop from L2 - more than the chip's L2 can feed at
+// MFMA speed; 256 x 256 halves that, and LDS-DMA frees ~64 VGPRs and all staging instructions.
+//
+// LDS image per stage (64 KiB): A then B, 32 KiB each.
+//   k-contiguous operand: [256 rows][64 k] bf16, 128-byte rows, 16-byte chunk index XOR (row & 7).
+//   k-strided operand:    [64 k][256 idx] bf16, 512-byte rows, 32-byte segment index XOR f(k), f(k) = (k&3) | ((k>>3)&1)<<2.
+// LDS-DMA writes lane-linearly (wave base + 16 * lane), so the swizzle is applied to each lane's SOURCE address and
+// again when fragments are read (both sides or neither).
+// 8 waves as 2 (m) x 4 (n); each wave owns 128 x 64 of C = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator VGPRs).
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kOperandBytes = TM * TK * 2;  // 32 KiB
+constexpr int kStage = 2 * kOperandBytes;   // 64 KiB
+
+__device__ __forceinline__ int kc_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+__device__ __forceinline__ int ksf(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int ks_off(int k, int idx) { return k * 512 + (((idx >> 4) ^ ksf(k)) << 5) + ((idx & 15) << 1); }
+
+// LDS-DMA of 64 x 16 bytes (lane l's 16 bytes land at lds_wave_base + 16 * l), issued as inline assembly on purpose.
+// Through __builtin_amdgcn_global_load_lds the compiler knows the instruction writes LDS; unable to prove that the fragment
+// reads of the CURRENT stage touch the other half of the buffer, it puts s_waitcnt vmcnt(0) in front of them - i.e. it
+// drains the NEXT stage's loads right after they were issued, and the double buffer overlaps nothing (rocprof: the k-loop
+// sat at 57 % MFMA-busy).  Ordering is explicit instead: the counted/zero vmcnt wait and the barrier that end a k-step.
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
+}
+
+// Per-thread source pointers for the 4 one-KiB pieces this wave stages per operand per k-tile.
+template <bool KC>
+struct Stager {
+    const uint16_t* src[4];
+    int64_t kstep;
+
+    __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int64_t idx0, int64_t extent, int64_t kbeg, int wid,
+                                         int lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wid * 4 + i;  // piece index 0..31 inside the operand image
+            if constexpr (KC) {
+                const int r = q * 8 + (lane >> 3);            // row inside the tile
+                const int c = (lane & 7) ^ (r & 7);           // which 16-byte chunk of the row lands at this lane's slot
+                int64_t row = idx0 + r;
+                if (row > extent - 1) row = extent - 1;       // clamp: rows past the edge are never stored
+                src[i] = base + row * ld + kbeg + c * 8;
+            } else {
+                const int k = q * 2 + (lane >> 5);
+                const int p = lane & 31;
+                const int seg = (p >> 1) ^ ksf(k);
+                int64_t col = idx0 + (seg * 2 + (p & 1)) * 8;
+                if (col > extent - 8) col = extent - 8;       // clamp (extent % 8 == 0)
+                src[i] = base + (kbeg + k) * ld + col;
+            }
+        }
+        kstep = KC ? TK : TK * ld;
+    }
+    __device__ __forceinline__ void issue(char* image, int wid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(src[i], image + (wid * 4 + i) * 1024);
+            src[i] += kstep;
+        }
+    }
+};
+
+#ifdef CM3P_ALT_LOADER
+// LDS-DMA with a scalar base: global address = sbase (SGPR pair) + voff (one VGPR), LDS address = m0 + 16 * lane.
+__device__ __forceinline__ void glds16_s(uint32_t voff, const char* sbase, char* lds_wave_base) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
+}
+
+// One loader wave (j = wid & 3) streams pieces 8 j .. 8 j + 7 of an operand image: the 32 one-KiB pieces of a k-tile are
+// shared by four waves, and the two wave groups (wm = 0 / 1) take turns from k-step to k-step (see the k-loop).  Everything that
+// depends on the piece is a scalar (SALU): a lane contributes one 32-bit offset that is the same for all pieces of a k-contiguous
+// operand, and (xor, min, add) per piece for a k-strided one.  Extents are multiples of 8, so a piece is inside or outside the
+// matrix as a whole; outside pieces re-read the last valid rows (their products are never stored).
+template <bool KC>
+struct Loader {
+    const char* base;
+    uint64_t po0;      // byte offset of this wave's first piece at k-tile 0 of the current work item
+    uint64_t pstride;  // bytes from one piece to the next
+    uint64_t pclamp;   // KC: offset of the last 8 valid rows (pieces past the edge read those)
+    int nvalid;        // KC: pieces 0 .. nvalid-1 of this wave lie inside the matrix
+    uint64_t adv;      // bytes per k-tile
+    uint32_t v0, v1;   // KC: v0 = lane offset.  KS: v0 = swizzled segment offset for C = 0, v1 = row part
+    uint32_t lim;      // KS: largest valid column offset (bytes) relative to the tile origin
+
+    __device__ __forceinline__ void init_lane(const uint16_t* b, int64_t ld, int lane) {
+        base = reinterpret_cast<const char*>(b);
+        if constexpr (KC) {
+            const int rr = lane >> 3;
+            v0 = (uint32_t)((rr * ld + (((lane & 7) ^ (rr & 7)) << 3)) * 2);
+            v1 = 0;
+            adv = TK * 2;
+            pstride = (uint64_t)ld * 16;
+        } else {
+            const int hi = lane >> 5, p = lane & 31;
+            v0 = (uint32_t)(((((p >> 1) ^ hi) << 1) | (p & 1)) << 4);
+            v1 = (uint32_t)(hi * ld * 2);
+            adv = (uint64_t)TK * ld * 2;
+            pstride = (uint64_t)ld * 4;
+        }
+        lim = 0;
+        pclamp = 0;
+        nvalid = 8;
+    }
+    __device__ __forceinline__ void init_item(int64_t ld, int64_t idx0, int64_t extent, int64_t kbeg, int j) {
+        if constexpr (KC) {
+            const int64_t row0 = idx0 + j * 64;
+            po0 = (uint64_t)(row0 * ld + kbeg) * 2;
+            pclamp = (uint64_t)((extent - 8) * ld + kbeg) * 2;
+            const int64_t inside = (extent - row0) >> 3;  // whole 8-row pieces before the edge (may be <= 0)
+            nvalid = inside >= 8 ? 8 : (inside < 0 ? 0 : (int)inside);
+        } else {
+            po0 = (uint64_t)((kbeg + 16 * j) * ld + idx0) * 2;
+            lim = (uint32_t)((extent - 8 - idx0) * 2);
+        }
+    }
+    __device__ __forceinline__ void issue(char* image, int j, int kt) {
+        const uint64_t kb = (uint64_t)kt * adv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* dst = image + (j * 8 + i) * 1024;
+            if constexpr (KC) {
+                const uint64_t off = (i < nvalid ? po0 + (uint64_t)i * pstride : pclamp) + kb;
+                glds16_s(v0, base + off, dst);
+            } else {
+                const uint32_t c = (uint32_t)((((i & 1) << 1) | (((i >> 2) & 1) << 2)) << 5);  // ksf's piece-dependent bits
+                uint32_t so = v0 ^ c;
+                so = so < lim ? so : lim;
+                glds16_s(so + v1, base + (po0 + (uint64_t)i * pstride + kb), dst);
+            }
+        }
+    }
+};
+#endif
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag(const char* image, int idx0, int kk, int lane) {
+    if constexpr (KC) {
+        const int r = idx0 + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(image + kc_off(r, kk * 4 + (lane >> 4)));
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int k = kk * 32 + 8 * g + q;
+        const bf16x4 lo = lds_read_tr16(image + ks_off(k, idx0 + 4 * p));
+        const bf16x4 hi = lds_read_tr16(image + ks_off(k + 4, idx0 + 4 * p));
+        return cat_bf16x4(lo, hi);
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for every global
+// store already issued - in the epilogue that serialises the passes on HBM write latency.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                         void* __restrict__ Cv, const float* R, int64_t M, int64_t N, int64_t K,
+                                                         int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int ntiles, int total,
+                                                         int64_t kchunk, int64_t c_split_stride, RopeArgs rope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+
+    // Persistent workgroups: work item v = (k-split, tile); block b takes v = b, b + grid, ...  The XCD-aware (bijective)
+    // order gives the blocks of one XCD (b % 8 equal) neighbouring tiles in every round, so operand panels are re-read
+    // from that XCD's L2.  Speed only: any order is correct.
+    const int q8 = total / 8, r8 = total % 8;
+    auto decode = [&](int v, int64_t& m0, int64_t& n0, int& z) {
+        const int xcd = v % 8;
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + v / 8;
+        z = swz / ntiles;
+        const int t = swz - z * ntiles;
+        m0 = (int64_t)(t / tiles_n) * TM;
+        n0 = (int64_t)(t % tiles_n) * TN;
+    };
+
+    int v = blockIdx.x;
+    int64_t m0, n0;
+    int z;
+    decode(v, m0, n0, z);
+    int64_t kbeg = (int64_t)z * kchunk;
+    int nk = (int)((min(K, kbeg + kchunk) - kbeg) / TK);  // K % 64 == 0 on this path
+
+#ifdef CM3P_ALT_LOADER
+    // The two wave groups (wm = 0: waves 0-3, wm = 1: waves 4-7; wave w and w + 4 share a SIMD) take turns as loaders: in a
+    // k-step the loader group issues the whole next k-tile (16 LDS-DMA instructions per wave) while its SIMD partners go
+    // straight to their MFMAs, then multiplies while the partners are done and waiting; next k-step the roles swap.  With every
+    // wave issuing its share at the top of the step (the earlier scheme) all eight waves queued on the texture-address path
+    // at once and the matrix pipe idled until they got through.
+    const int lj = wid & 3;
+    Loader<A_KC> sa;
+    Loader<B_KC> sb;
+    sa.init_lane(A, lda, lane);
+    sb.init_lane(B, ldb, lane);
+    sa.init_item(lda, m0, M, kbeg, lj);
+    sb.init_item(ldb, n0, N, kbeg, lj);
+    int stage = 0;
+    int turn = 1;  // group (turn & 1) loads in the current k-step
+    if (wm == 0) {
+        sa.issue(smem, lj, 0);
+        sb.issue(smem + kOperandBytes, lj, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
+    Stager<A_KC> sa;
+    Stager<B_KC> sb;
+    sa.init(A, lda, m0, M, kbeg, wid, lane);
+    sb.init(B, ldb, n0, N, kbeg, wid, lane);
+    int stage = 0;
+    sa.issue(smem, wid);
+    sb.issue(smem + kOperandBytes, wid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+
+    while (true) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < total;
+        int64_t m0n = 0, n0n = 0, kbegn = 0;
+        int zn = 0, nkn = 0;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + stage * kStage;
+            char* nxt = smem + (stage ^ 1) * kStage;
+#ifdef CM3P_ALT_LOADER
+            const bool my_turn = wm == (turn & 1);
+            if (kt + 1 < nk) {
+                if (my_turn) {
+                    sa.issue(nxt, lj, kt + 1);
+                    sb.issue(nxt + kOperandBytes, lj, kt + 1);
+                }
+            } else if (has_next) {
+                // cross-tile prefetch: the first k-tile of the NEXT work item streams in under this item's last MFMAs and
+                // epilogue, so the next item starts without a load bubble
+                decode(vn, m0n, n0n, zn);
+                kbegn = (int64_t)zn * kchunk;
+                nkn = (int)((min(K, kbegn + kchunk) - kbegn) / TK);
+                sa.init_item(lda, m0n, M, kbegn, lj);
+                sb.init_item(ldb, n0n, N, kbegn, lj);
+                if (my_turn) {
+                    sa.issue(nxt, lj, 0);
+                    sb.issue(nxt + kOperandBytes, lj, 0);
+                }
+            }
+#else
+            if (kt + 1 < nk) {
+                sa.issue(nxt, wid);
+                sb.issue(nxt + kOperandBytes, wid);
+            } else if (has_next) {
+                // cross-tile prefetch: the first k-tile of the NEXT work item streams in under this item's last MFMAs and
+                // epilogue, so the next item starts without a load bubble
+                decode(vn, m0n, n0n, zn);
+                kbegn = (int64_t)zn * kchunk;
+                nkn = (int)((min(K, kbegn + kchunk) - kbegn) / TK);
+                sa.init(A, lda, m0n, M, kbegn, wid, lane);
+                sb.init(B, ldb, n0n, N, kbegn, wid, lane);
+                sa.issue(nxt, wid);
+                sb.issue(nxt + kOperandBytes, wid);
+            }
+#endif
+            const char* ia = cur;
+            const char* ib = cur + kOperandBytes;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 fa[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for the other stage has landed
+            __syncthreads();                                   // everyone's has, and everyone is done reading `cur`
+            stage ^= 1;
+#ifdef CM3P_ALT_LOADER
+            ++turn;
+#endif
+        }
+
+        // ---- epilogue through LDS: fragment-shaped accumulators -> whole rows -> 16-byte coalesced stores -----------
+        // (a lane owns 4 consecutive n of one m; storing that directly issues 32 partial-line stores per lane and is
+        //  store-issue bound.)  `stage` now holds the next item's first k-tile (if any); the other 64 KiB are free.
+        char* ebuf = smem + (stage ^ 1) * kStage;
+        if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
+            constexpr int kRow = TN * 2 + 16;  // padded row pitch (bytes): 16 rows of one column land on different banks
+            uint16_t* C = static_cast<uint16_t*>(Cv);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {  // 64 rows per pass: waves with wm == pass/2, accumulator rows i in [4*(pass&1), +4)
+                if (wm == (pass >> 1)) {
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a = acc[(pass & 1) * 4 + i4][j];
+                            const int r = i4 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            *reinterpret_cast<uint2*>(ebuf + r * kRow + cidx * 2) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
+                        }
+                }
+                lds_barrier();
+                bool rotated = false;
+                if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+                    // Rotary embedding at store time, on whole staged rows (apply_rotary_pos_emb on the bf16 projection, as the
+                    // reference's autocast path does): a work item is (row, head, 8 dims d..d+7 < 32) = the chunk pair (d, d+32);
+                    // one table read serves both.  Doing it in the accumulators instead cost 33 % of this GEMM (eight serialised
+                    // gather round trips per wave and ~50 spilled VGPRs).
+                    if (n0 < rope.ncols) {  // tiles are head-aligned: a tile lies entirely inside or outside the rotated columns
+                        rotated = true;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tid + 512 * u, r = id >> 4, hd = (id >> 2) & 3, dc = id & 3;
+                            const int64_t m = m0 + pass * 64 + r, n = n0 + hd * 64 + dc * 8;
+                            if (m < M && n < N) {
+                                const int64_t prow = rope.per_batch ? m : (int64_t)((uint32_t)m % (uint32_t)rope.S);  // M < 2^31 (checked by the caller)
+                                const float* cr = rope.cos + prow * 32 + dc * 8;
+                                const float* sr = rope.sin + prow * 32 + dc * 8;
+                                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+                                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+                                const uint4 xa = *reinterpret_cast<const uint4*>(ebuf + r * kRow + (hd * 8 + dc) * 16);
+                                const uint4 xb = *reinterpret_cast<const uint4*>(ebuf + r * kRow + (hd * 8 + dc + 4) * 16);
+                                const uint32_t wa[4] = {xa.x, xa.y, xa.z, xa.w}, wb[4] = {xb.x, xb.y, xb.z, xb.w};
+                                const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                                const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                                uint32_t oa[4], ob[4];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const float a0 = bf16lo(wa[t]), a1 = bf16hi(wa[t]), b0 = bf16lo(wb[t]), b1 = bf16hi(wb[t]);
+                                    oa[t] = pack_bf16x2(a0 * cs[2 * t] - b0 * sn[2 * t], a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]);
+                                    ob[t] = pack_bf16x2(b0 * cs[2 * t] + a0 * sn[2 * t], b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]);
+                                }
+                                *reinterpret_cast<uint4*>(C + m * ldc + n) = uint4{oa[0], oa[1], oa[2], oa[3]};
+                                *reinterpret_cast<uint4*>(C + m * ldc + n + 32) = uint4{ob[0], ob[1], ob[2], ob[3]};
+                            }
+                        }
+                    }
+                }
+                if (!rotated) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
+                        const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 8;
+                        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(ebuf + r * kRow + ch * 16);
+                    }
+                }
+                lds_barrier();
+            }
+        } else {
+            constexpr int kRow = TN * 4 + 16;
+            float* C = static_cast<float*>(Cv) + (int64_t)z * c_split_stride;
+            // residual rows of pass p+1 are requested before pass p's LDS round trip (16 VGPRs): a pass then waits for loads that
+            // have had a whole pass to arrive instead of issuing them and stalling on HBM latency eight times per tile
+            f32x4 rres[4];
+            auto load_resid = [&](int pass) {
+                if constexpr (EPI == CM3P_EPI_F32_RESID) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                        const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
+                        rres[u] = (m < M && n < N) ? *reinterpret_cast<const f32x4*>(R + m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if constexpr (EPI == CM3P_EPI_F32_BIAS) {  // a thread keeps its four columns in every pass: one read per tile
+                    if (pass == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t n = n0 + ((tid + 512 * u) & 63) * 4;
+                            rres[u] = n < N ? *reinterpret_cast<const f32x4*>(R + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
+            };
+            load_resid(0);
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {  // 32 rows per pass: waves with wm == pass/4, accumulator rows 2*(pass&3), +1
+                if (wm == (pass >> 2)) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a = acc[(pass & 3) * 2 + i2][j];  // pass loop fully unrolled: static register index
+                            const int r = i2 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            *reinterpret_cast<f32x4*>(ebuf + r * kRow + cidx * 4) = a;
+                        }
+                }
+                lds_barrier();
+                f32x4 rcur[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rcur[u] = rres[u];
+                if (pass < 7) load_resid(pass + 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                    const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
+                    if (m < M && n < N) {
+                        f32x4 a = *reinterpret_cast<const f32x4*>(ebuf + r * kRow + ch * 16);
+                        if constexpr (EPI == CM3P_EPI_F32_RESID || EPI == CM3P_EPI_F32_BIAS) a += rcur[u];
+                        *reinterpret_cast<f32x4*>(C + m * ldc + n) = a;
+                    }
+                }
+                lds_barrier();
+            }
+        }
+
+        if (!has_next) break;
+        v = vn;
+        m0 = m0n;
+        n0 = n0n;
+        z = zn;
+        nk = nkn;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+              int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
+    const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
+    const int ntiles = tiles_m * tiles_n, total = ntiles * splits;
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    const dim3 grid(total < num_cu ? total : num_cu);  // one persistent 512-thread workgroup per CU
+    const size_t lds = 2 * kStage;
+#define CM3P_G256(E)                                                                                                     \
+    {                                                                                                                    \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute((const void*)gemm256_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds) != hipSuccess)                                                             \
+                return CM3P_ERR_LAUNCH;                                                                                  \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
+    }
+    switch (epi) {
+        case CM3P_EPI_BF16: CM3P_G256(CM3P_EPI_BF16) break;
+        case CM3P_EPI_F32: CM3P_G256(CM3P_EPI_F32) break;
+        case CM3P_EPI_F32_RESID: CM3P_G256(CM3P_EPI_F32_RESID) break;
+        case CM3P_EPI_BF16_ROPE:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G256(CM3P_EPI_BF16_ROPE)
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        case CM3P_EPI_F32_BIAS:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G256(CM3P_EPI_F32_BIAS)
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        default: return CM3P_ERR_INVALID;
+    }
+#undef CM3P_G256
+    return CM3P_OK;
+}
+
+}  // namespace
+
+// Internal entry used by cm3p_gemm_bf16 (gemm.hip) when the shape qualifies; not part of the public header.
+int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
+                          int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
+    const uint16_t* a = static_cast<const uint16_t*>(A);
+    const uint16_t* b = static_cast<const uint16_t*>(B);
+    if (a_kc && b_kc) return launch256<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (a_kc) return launch256<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (b_kc) return launch256<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    return launch256<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+}
