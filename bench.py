@@ -258,10 +258,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Per-kernel timing.  One extra UNTIMED step with a HIP-event pair around every C-ABI call gives the breakdown and names the
+    # dominant single kernel; inside the timed region only that kernel's launches are bracketed (every launch bracketed costs
+    # the stream ~5 ms per C2 step, which would be charged to the judged number).
     profile = not args.no_profile
+    prof_all, dom_tag = {}, None
+    if profile:
+        fence()
+        _lib.profile_begin()
+        step()
+        prof_all = _lib.profile_end()
+        single = {k: v for k, v in prof_all.items() if k.startswith(("gemm", "attn_fwd"))}
+        dom_tag = max(single.items(), key=lambda kv: kv[1][1])[0]
     fence()
     if profile:
-        _lib.profile_begin()
+        _lib.profile_begin(only=dom_tag)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -303,21 +314,20 @@ def main():
             result["optimizer_step"] = opt_info
     if rank == 0:
         if prof:
-            total_ms = sum(v[1] for v in prof.values())
             # dominant SINGLE kernel (tags of C-ABI calls that launch several kernels are listed in the breakdown only, so
-            # that the figure can be checked against one row of the rocprofv3 --stats summary)
-            single = {k: v for k, v in prof.items() if k.startswith(("gemm", "attn_fwd"))}
-            tag, (n, ms, work) = max(single.items(), key=lambda kv: kv[1][1])
+            # that the figure can be checked against one row of the rocprofv3 --stats summary); its launches were timed with
+            # HIP events inside the timed region, on the stream they run on
+            tag, (n, ms, work) = dom_tag, prof[dom_tag]
+            total_ms = sum(v[1] for v in prof_all.values())  # one fully bracketed (untimed) step
             achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             result["roofline"] = {
                 "kernel": tag, "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, tag),
-                "launches": n, "avg_launch_ms": ms / n, "share_of_kernel_time": ms / total_ms,
+                "launches": n, "avg_launch_ms": ms / n, "share_of_kernel_time": (ms / args.steps) / total_ms,
                 "flop_per_launch": work / n,
             }
-            result["kernel_breakdown_ms_per_step"] = {
-                k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]
-            }
+            result["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])[:12]}
+            result["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
         if world == 1 and not args.no_cpu_baseline and not w.get("mlm"):  # (the oracle's timed leg covers the BASELINE workloads)
             result["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(result), flush=True)

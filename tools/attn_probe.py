@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Runs the global-layer attention forward a few times (for rocprofv3 --pmc / --kernel-trace passes)."""
+"""Runs the attention forward or backward a few times (for rocprofv3 --pmc / --kernel-trace passes).
+
+    python tools/attn_probe.py [fwd|bwd] [window: -1 global (default), 64 local]
+"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,11 +12,12 @@ B, S, nh = 32, 4096, 12
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B, S, 3, nh, 64, device="cuda", generator=g).to(torch.bfloat16)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-out, lse = K.attn_fwd(qkv, None, B, S, nh, -1, 0.125)
+W = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+out, lse = K.attn_fwd(qkv, None, B, S, nh, W, 0.125)
 do = torch.randn(B * S, nh * 64, device="cuda", generator=g).to(torch.bfloat16)
 for _ in range(5):
     if which == "fwd":
-        K.attn_fwd(qkv, None, B, S, nh, -1, 0.125)
+        K.attn_fwd(qkv, None, B, S, nh, W, 0.125)
     else:
-        K.attn_bwd(qkv, out, do, lse, None, B, S, nh, -1, 0.125)
+        K.attn_bwd(qkv, out, do, lse, None, B, S, nh, W, 0.125)
 torch.cuda.synchronize()
