@@ -163,21 +163,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
             }
             const char* ia = cur;
             const char* ib = cur + kOperandBytes;
+            if constexpr (A_KC) {
+                // Forward and input-gradient GEMMs: the k-step's 64 MFMAs run as four groups of 16 (g = 2 kk + half) and the
+                // fragments of group g + 1 are requested before the MFMAs of group g are issued (left alone, the compiler sinks each
+                // group's ds_reads next to their use), so only the first group's LDS latency is exposed: one-call A/B dgrad -8 %,
+                // forward -1..3 %.  The weight-gradient GEMM (both operands read through ds_read_b64_tr_b16, twice the read
+                // instructions) lost 2-4 % with the same schedule and keeps the plain loop below.
+                bf16x8 fbq[2][4], faq[2][4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fb[4];
+                for (int j = 0; j < 4; ++j) fbq[0][j] = frag<B_KC>(ib, wn * 64 + j * 16, 0, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
+                for (int i = 0; i < 4; ++i) faq[0][i] = frag<A_KC>(ia, wm * 128 + i * 16, 0, lane);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    bf16x8 fa[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int kk = g >> 1, half = g & 1;
+                    if (g < 3) {
+                        const int kn = (g + 1) >> 1, hn = (g + 1) & 1;
+                        if (hn == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
+                            for (int j = 0; j < 4; ++j) fbq[kn & 1][j] = frag<B_KC>(ib, wn * 64 + j * 16, kn, lane);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) faq[(g + 1) & 1][i] = frag<A_KC>(ia, wm * 128 + (hn * 4 + i) * 16, kn, lane);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
+                            acc[half * 4 + i][j] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbq[kk & 1][j], faq[g & 1][i], acc[half * 4 + i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay above these MFMAs
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 fb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 fa[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[i] = frag<A_KC>(ia, wm * 128 + (half * 4 + i) * 16, kk, lane);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for the other stage has landed
