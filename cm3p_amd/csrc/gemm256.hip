@@ -147,10 +147,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + stage * kStage;
             char* nxt = smem + (stage ^ 1) * kStage;
-            if (kt + 1 < nk) {
-                sa.issue(nxt, wid);
-                sb.issue(nxt + kOperandBytes, wid);
-            } else if (has_next) {
+            // Steady state: the next k-tile of this work item.  In the forward / input-gradient instances the two waves of a SIMD
+            // (w and w + 4) issue it at different points of the k-step - waves 0-3 before their first MFMA group, waves 4-7 after
+            // it: an LDS-DMA instruction holds its wave's issue port for 40-70 cycles (tools/ubench/lds_dma_issue.hip), and with
+            // all eight waves issuing at the top of the step the matrix pipe idles for the whole burst (one-call A/B: dgrad -4 %,
+            // forward -2 %).  Issuing later than that (after group 1 or 2) costs 5-10 %: with two 64 KiB stages those loads no
+            // longer land before the barrier that ends the step.  The weight-gradient instance gained nothing and issues at the top.
+            const bool steady = kt + 1 < nk;
+            auto issue_at = [&](int g) {
+                if (steady && g == ((A_KC && wm == 1) ? 0 : -1)) {
+                    sa.issue(nxt, wid);
+                    sb.issue(nxt + kOperandBytes, wid);
+                }
+            };
+            if (!steady && has_next) {
                 // cross-tile prefetch: the first k-tile of the NEXT work item streams in under this item's last MFMAs and
                 // epilogue, so the next item starts without a load bubble
                 decode(vn, m0n, n0n, zn);
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                 sa.issue(nxt, wid);
                 sb.issue(nxt + kOperandBytes, wid);
             }
+            issue_at(-1);
             const char* ia = cur;
             const char* ib = cur + kOperandBytes;
             if constexpr (A_KC) {
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                             acc[half * 4 + i][j] =
                                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbq[kk & 1][j], faq[g & 1][i], acc[half * 4 + i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay above these MFMAs
+                    issue_at(g);
                 }
             } else {
 #pragma unroll
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
+                        issue_at(kk * 2 + half);
                     }
                 }
             }
