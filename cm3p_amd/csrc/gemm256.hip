@@ -61,13 +61,21 @@ struct Stager {
             }
         }
         kstep = KC ? TK : TK * ld;
-    }
-    __device__ __forceinline__ void issue(char* image, int wid) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(src[i], image + (wid * 4 + i) * 1024);
-            src[i] += kstep;
-        }
+        for (int i = 0; i < 4; ++i) src[i] -= i * 512;  // (elements) compensates the instruction offset of piece i
+    }
+    // one m0 write for the wave's four consecutive 1-KiB pieces: the instruction offset moves the LDS address (and the global
+    // address, which is why src[i] is kept i KiB low - see init)
+    __device__ __forceinline__ void issue(char* image, int wid) {
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(image + wid * 4096));
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %3, off offset:3072" ::"v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(m0v)
+                     : "memory", "m0");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) src[i] += kstep;
     }
 };
 
