@@ -17,6 +17,18 @@
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
+// Wave layout: 2 waves along m x kWN along n.  kWN = 4 (shipped): eight waves of 128 x 64, two per SIMD.  kWN = 2 builds four
+// waves of 128 x 128 (one per SIMD, 256 accumulator AGPRs; a k-step then reads 128 KiB of fragments from LDS instead of 192 KiB):
+// correct, but 10-30 % slower in a one-call A/B - a lone wave per SIMD cannot hide its own LDS-DMA issue and read latency.
+#ifndef CM3P_G256_WN
+#define CM3P_G256_WN 4
+#endif
+constexpr int kWN = CM3P_G256_WN;
+constexpr int kThreads = 128 * kWN;      // 512 or 256
+constexpr int kNJ = 16 / kWN;            // 16-column MFMA tiles per wave: 4 or 8
+constexpr int kWaveN = TN / kWN;         // 64 or 128
+constexpr int kPieces = 16 / kWN;        // 1-KiB LDS-DMA pieces per wave, operand and k-tile: 4 or 8
+constexpr int kItems = 2048 / kThreads;  // 16-byte store items per thread and epilogue pass: 4 or 8
 constexpr int kOperandBytes = TM * TK * 2;  // 32 KiB
 constexpr int kStage = 2 * kOperandBytes;   // 64 KiB
 
@@ -37,14 +49,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // Per-thread source pointers for the 4 one-KiB pieces this wave stages per operand per k-tile.
 template <bool KC>
 struct Stager {
-    const uint16_t* src[4];
+    const uint16_t* src[kPieces];
     int64_t kstep;
 
     __device__ __forceinline__ void init(const uint16_t* base, int64_t ld, int64_t idx0, int64_t extent, int64_t kbeg, int wid,
                                          int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = wid * 4 + i;  // piece index 0..31 inside the operand image
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = wid * kPieces + i;  // piece index 0..31 inside the operand image
             if constexpr (KC) {
                 const int r = q * 8 + (lane >> 3);            // row inside the tile
                 const int c = (lane & 7) ^ (r & 7);           // which 16-byte chunk of the row lands at this lane's slot
@@ -62,20 +74,25 @@ struct Stager {
         }
         kstep = KC ? TK : TK * ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] -= i * 512;  // (elements) compensates the instruction offset of piece i
+        for (int i = 0; i < kPieces; ++i) src[i] -= (i & 3) * 512;  // (elements) compensates the instruction offset of piece i
     }
     // one m0 write for the wave's four consecutive 1-KiB pieces: the instruction offset moves the LDS address (and the global
     // address, which is why src[i] is kept i KiB low - see init)
     __device__ __forceinline__ void issue(char* image, int wid) {
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(image + wid * 4096));
-        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %0, off\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %2, off offset:2048\n\t"
-                     "global_load_lds_dwordx4 %3, off offset:3072" ::"v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(m0v)
-                     : "memory", "m0");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] += kstep;
+        for (int g4 = 0; g4 < kPieces / 4; ++g4) {
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(image + (wid * kPieces + g4 * 4) * 1024));
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %0, off\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %2, off offset:2048\n\t"
+                         "global_load_lds_dwordx4 %3, off offset:3072" ::"v"(src[g4 * 4]), "v"(src[g4 * 4 + 1]), "v"(src[g4 * 4 + 2]),
+                         "v"(src[g4 * 4 + 3]), "s"(m0v)
+                         : "memory", "m0");
+        }
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) src[i] += kstep;
     }
 };
 
@@ -101,14 +118,14 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+__global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                          void* __restrict__ Cv, const float* R, int64_t M, int64_t N, int64_t K,
                                                          int64_t lda, int64_t ldb, int64_t ldc, int tiles_n, int ntiles, int total,
                                                          int64_t kchunk, int64_t c_split_stride, RopeArgs rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid / kWN, wn = wid % kWN;
 
     // Persistent workgroups: work item v = (k-split, tile); block b takes v = b, b + grid, ...  The XCD-aware (bijective)
     // order gives the blocks of one XCD (b % 8 equal) neighbouring tiles in every round, so operand panels are re-read
@@ -141,11 +158,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
     __syncthreads();
 
     while (true) {
-        f32x4 acc[8][4];
+        f32x4 acc[8][kNJ];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < kNJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         const int vn = v + gridDim.x;
         const bool has_next = vn < total;
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
             // longer land before the barrier that ends the step.  The weight-gradient instance gained nothing and issues at the top.
             const bool steady = kt + 1 < nk;
             auto issue_at = [&](int g) {
-                if (steady && g == ((A_KC && wm == 1) ? 0 : -1)) {
+                if (steady && g == ((A_KC && kWN == 4 && wm == 1) ? 0 : -1)) {
                     sa.issue(nxt, wid);
                     sb.issue(nxt + kOperandBytes, wid);
                 }
@@ -188,9 +205,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                 // group's ds_reads next to their use), so only the first group's LDS latency is exposed: one-call A/B dgrad -8 %,
                 // forward -1..3 %.  The weight-gradient GEMM (both operands read through ds_read_b64_tr_b16, twice the read
                 // instructions) lost 2-4 % with the same schedule and keeps the plain loop below.
-                bf16x8 fbq[2][4], faq[2][4];
+                bf16x8 fbq[2][kNJ], faq[2][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fbq[0][j] = frag<B_KC>(ib, wn * 64 + j * 16, 0, lane);
+                for (int j = 0; j < kNJ; ++j) fbq[0][j] = frag<B_KC>(ib, wn * kWaveN + j * 16, 0, lane);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) faq[0][i] = frag<A_KC>(ia, wm * 128 + i * 16, 0, lane);
 #pragma unroll
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                         const int kn = (g + 1) >> 1, hn = (g + 1) & 1;
                         if (hn == 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) fbq[kn & 1][j] = frag<B_KC>(ib, wn * 64 + j * 16, kn, lane);
+                            for (int j = 0; j < kNJ; ++j) fbq[kn & 1][j] = frag<B_KC>(ib, wn * kWaveN + j * 16, kn, lane);
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) faq[(g + 1) & 1][i] = frag<A_KC>(ia, wm * 128 + (hn * 4 + i) * 16, kn, lane);
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < kNJ; ++j)
                             acc[half * 4 + i][j] =
                                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbq[kk & 1][j], faq[g & 1][i], acc[half * 4 + i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);  // the next group's reads stay above these MFMAs
@@ -217,9 +234,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 fb[4];
+                    bf16x8 fb[kNJ];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[j] = frag<B_KC>(ib, wn * 64 + j * 16, kk, lane);
+                    for (int j = 0; j < kNJ; ++j) fb[j] = frag<B_KC>(ib, wn * kWaveN + j * 16, kk, lane);
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         bf16x8 fa[4];
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < kNJ; ++j)
                                 acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[half * 4 + i][j], 0, 0, 0);
                         issue_at(kk * 2 + half);
                     }
@@ -252,9 +269,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
                     for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < kNJ; ++j) {
                             const f32x4 a = acc[(pass & 1) * 4 + i4][j];
-                            const int r = i4 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            const int r = i4 * 16 + (lane & 15), cidx = wn * kWaveN + j * 16 + 4 * (lane >> 4);
                             *reinterpret_cast<uint2*>(ebuf + r * kRow + cidx * 2) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
                         }
                 }
@@ -268,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                     if (n0 < rope.ncols) {  // tiles are head-aligned: a tile lies entirely inside or outside the rotated columns
                         rotated = true;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int id = tid + 512 * u, r = id >> 4, hd = (id >> 2) & 3, dc = id & 3;
+                        for (int u = 0; u < kItems / 2; ++u) {
+                            const int id = tid + kThreads * u, r = id >> 4, hd = (id >> 2) & 3, dc = id & 3;
                             const int64_t m = m0 + pass * 64 + r, n = n0 + hd * 64 + dc * 8;
                             if (m < M && n < N) {
                                 const int64_t prow = rope.per_batch ? m : (int64_t)((uint32_t)m % (uint32_t)rope.S);  // M < 2^31 (checked by the caller)
@@ -297,8 +314,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                 }
                 if (!rotated) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int id = tid + 512 * u, r = id >> 5, ch = id & 31;
+                    for (int u = 0; u < kItems; ++u) {
+                        const int id = tid + kThreads * u, r = id >> 5, ch = id & 31;
                         const int64_t m = m0 + pass * 64 + r, n = n0 + ch * 8;
                         if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = *reinterpret_cast<const uint4*>(ebuf + r * kRow + ch * 16);
                     }
@@ -310,12 +327,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
             float* C = static_cast<float*>(Cv) + (int64_t)z * c_split_stride;
             // residual rows of pass p+1 are requested before pass p's LDS round trip (16 VGPRs): a pass then waits for loads that
             // have had a whole pass to arrive instead of issuing them and stalling on HBM latency eight times per tile
-            f32x4 rres[4];
+            f32x4 rres[kItems];
             auto load_resid = [&](int pass) {
                 if constexpr (EPI == CM3P_EPI_F32_RESID) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                    for (int u = 0; u < kItems; ++u) {
+                        const int id = tid + kThreads * u, r = id >> 6, ch = id & 63;
                         const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
                         rres[u] = (m < M && n < N) ? *reinterpret_cast<const f32x4*>(R + m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -323,8 +340,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
                 if constexpr (EPI == CM3P_EPI_F32_BIAS) {  // a thread keeps its four columns in every pass: one read per tile
                     if (pass == 0) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int64_t n = n0 + ((tid + 512 * u) & 63) * 4;
+                        for (int u = 0; u < kItems; ++u) {
+                            const int64_t n = n0 + ((tid + kThreads * u) & 63) * 4;
                             rres[u] = n < N ? *reinterpret_cast<const f32x4*>(R + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                     }
@@ -337,20 +354,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const uint16_t* __restr
 #pragma unroll
                     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < kNJ; ++j) {
                             const f32x4 a = acc[(pass & 3) * 2 + i2][j];  // pass loop fully unrolled: static register index
-                            const int r = i2 * 16 + (lane & 15), cidx = wn * 64 + j * 16 + 4 * (lane >> 4);
+                            const int r = i2 * 16 + (lane & 15), cidx = wn * kWaveN + j * 16 + 4 * (lane >> 4);
                             *reinterpret_cast<f32x4*>(ebuf + r * kRow + cidx * 4) = a;
                         }
                 }
                 lds_barrier();
-                f32x4 rcur[4];
+                f32x4 rcur[kItems];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rcur[u] = rres[u];
+                for (int u = 0; u < kItems; ++u) rcur[u] = rres[u];
                 if (pass < 7) load_resid(pass + 1);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int id = tid + 512 * u, r = id >> 6, ch = id & 63;
+                for (int u = 0; u < kItems; ++u) {
+                    const int id = tid + kThreads * u, r = id >> 6, ch = id & 63;
                     const int64_t m = m0 + pass * 32 + r, n = n0 + ch * 4;
                     if (m < M && n < N) {
                         f32x4 a = *reinterpret_cast<const f32x4*>(ebuf + r * kRow + ch * 16);
@@ -394,7 +411,7 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
                 return CM3P_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        gemm256_kernel<A_KC, B_KC, E><<<grid, 512, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
+        gemm256_kernel<A_KC, B_KC, E><<<grid, kThreads, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G256(CM3P_EPI_BF16) break;
