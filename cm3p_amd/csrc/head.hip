@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ce_masked_stats_kernel(const float* __res
 }
 
 constexpr int kDlRows = 64;   // rows per workgroup
-constexpr int kDlQuads = 4;   // 4-column groups per thread: covers pitch <= 4 * 256 * 4 = 4096 columns
+constexpr int kDlQuads = 4;   // 4-column groups per thread: a workgroup covers a window of 4 * 256 * 4 = 4096 columns (grid.y windows)
 
 __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __restrict__ logits, int cols, int64_t pitch, int64_t rows,
                                                                 const int64_t* __restrict__ target, int64_t ignore_index,
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __r
                                                                 float* __restrict__ partial) {
     const float s = scale_a[0] * scale_b[0];
     const int quads = (int)(pitch / 4);
+    const int qbase = blockIdx.y * 256 * kDlQuads;  // this workgroup's window of 4-column groups (4096 columns per window)
     f32x4 acc[kDlQuads];
 #pragma unroll
     for (int q = 0; q < kDlQuads; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __r
         if (t == ignore_index) {
 #pragma unroll
             for (int q = 0; q < kDlQuads; ++q) {
-                const int c4 = threadIdx.x + 256 * q;
+                const int c4 = qbase + threadIdx.x + 256 * q;
                 if (c4 < quads) *reinterpret_cast<uint2*>(drow + 4 * c4) = uint2{0u, 0u};
             }
             continue;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __r
         const float lse = ls[r - r0];
 #pragma unroll
         for (int q = 0; q < kDlQuads; ++q) {
-            const int c4 = threadIdx.x + 256 * q;
+            const int c4 = qbase + threadIdx.x + 256 * q;
             if (c4 < quads) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * c4);
                 f32x4 g;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __r
     }
 #pragma unroll
     for (int q = 0; q < kDlQuads; ++q) {
-        const int c4 = threadIdx.x + 256 * q;
+        const int c4 = qbase + threadIdx.x + 256 * q;
         if (c4 < quads) *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * pitch + 4 * c4) = acc[q];
     }
 }
@@ -478,11 +479,12 @@ int cm3p_ce_masked_dlogits_bf16(const float* logits, int64_t rows, int cols, int
                                 const float* lse_rows, const float* scale_a, const float* scale_b, void* dlogits_bf16, float* partial,
                                 float* colsum, void* stream) {
     CM3P_REQUIRE(logits && target && lse_rows && scale_a && scale_b && dlogits_bf16 && partial && colsum && rows > 0 && cols > 0);
-    CM3P_REQUIRE(row_stride >= cols && row_stride % 4 == 0 && row_stride <= 4 * 256 * kDlQuads && cm3p_aligned16(logits) &&
+    CM3P_REQUIRE(row_stride >= cols && row_stride % 4 == 0 && cm3p_aligned16(logits) &&
                  cm3p_aligned16(partial) && (reinterpret_cast<uintptr_t>(dlogits_bf16) & 7) == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nblk = cm3p_ce_masked_dlogits_blocks(rows);
-    ce_masked_dlogits_kernel<<<nblk, 256, 0, s>>>(logits, cols, row_stride, rows, target, ignore_index, lse_rows, scale_a, scale_b,
+    const dim3 dgrid(nblk, (unsigned)((row_stride + 4 * 256 * kDlQuads - 1) / (4 * 256 * kDlQuads)));
+    ce_masked_dlogits_kernel<<<dgrid, 256, 0, s>>>(logits, cols, row_stride, rows, target, ignore_index, lse_rows, scale_a, scale_b,
                                                   (uint16_t*)dlogits_bf16, partial);
     CM3P_LAUNCH_CHECK();
     colsum_final_kernel<<<(int)((row_stride + 63) / 64), 256, 0, s>>>(partial, colsum, nblk, (int)row_stride);

@@ -230,7 +230,7 @@ int cm3p_inv_valid_count(const int64_t* target, int64_t n, int64_t ignore_index,
  * cm3p_ce_masked_dlogits_bf16: dlogits_bf16[r, c] = bf16(s * (exp(x[r, c] - lse_r) - [c == target_r])), s = scale_a[0] * scale_b[0]
  *   (device scalars: the incoming loss gradient and 1 / #labelled), zero for ignored rows and pad columns - the operand of the
  *   decoder's dgrad / wgrad GEMMs; colsum[c] = sum_r of the unrounded values (the decoder bias gradient, fixed order).
- *   row_stride % 4 == 0 and <= 4096; partial: [cm3p_ce_masked_dlogits_blocks(rows), row_stride] fp32 workspace. */
+ *   row_stride % 4 == 0; partial: [cm3p_ce_masked_dlogits_blocks(rows), row_stride] fp32 workspace. */
 int cm3p_ce_masked_stats(const float* logits, int64_t rows, int cols, int64_t row_stride, const int64_t* target, int64_t ignore_index,
                          float* loss_rows, float* lse_rows, void* stream);
 int cm3p_ce_masked_dlogits_blocks(int64_t rows);

@@ -443,7 +443,7 @@ def test_head_kernels(K):
     _assert_close(d, Lr.grad, 1e-7, 1e-5, "clip dlogits")
 
 
-@pytest.mark.parametrize("rows,vocab,frac", [(300, 3167, 0.15), (70, 37, 0.5), (129, 1000, 0.0), (64, 3167, 1.0)])
+@pytest.mark.parametrize("rows,vocab,frac", [(300, 3167, 0.15), (70, 37, 0.5), (129, 1000, 0.0), (64, 3167, 1.0), (130, 9001, 0.3)])
 def test_masked_lm_loss_kernels(K, rows, vocab, frac):
     """cm3p_ce_masked_stats / cm3p_ce_masked_dlogits_bf16 / cm3p_inv_valid_count / cm3p_sum_f32 against
     F.cross_entropy(ignore_index=-100) (TF:loss/loss_utils.py:32-46): loss within fp32 summation-order error, the bf16 gradient
