@@ -32,3 +32,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and ("traffic" in r)
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and c["unit"] == "pairs/s"
+
+
+def test_bench_two_ranks_share_the_card_over_gloo():
+    """The N > 1 code path of bench.py (DDP wrapper, gathered negatives, barrier + max-over-ranks timing, rank 0 prints) rehearsed
+    with two ranks on the one GPU of this box; the driver's runs use one rank per GPU over RCCL."""
+    env = dict(os.environ, CM3P_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-optimizer"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"].startswith("dp2")
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]  # whole-job pairs/s
+    assert "cpu_baseline" not in d  # (rank 0 at N = 1 only)
