@@ -114,13 +114,18 @@ def _check(rc: int, name: str):
         raise Cm3pHipError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
 
 
-def ptr(t: torch.Tensor | None):
+def ptr(t: torch.Tensor | None, dtype: torch.dtype | None = None):
+    """Device address of a contiguous GPU tensor.  `dtype`: what the C entry point reads there - a kernel handed int32 token ids
+    where it reads int64 walks off the end of the embedding table (a GPU memory fault, not an exception), so every index / mask /
+    single-dtype argument is checked here and a mismatch is a TypeError."""
     if t is None:
         return None
     if not t.is_cuda:
         raise Cm3pHipError("cm3p_amd kernels need GPU tensors; there is no CPU fallback")
     if not t.is_contiguous():
         raise Cm3pHipError("cm3p_amd kernels need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"cm3p_amd kernel argument has dtype {t.dtype}, the kernel reads {dtype}")
     return t.data_ptr()
 
 

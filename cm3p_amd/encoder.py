@@ -362,6 +362,8 @@ class CM3PEncoder(nn.Module):
         cfg = self.config
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if input_ids is not None and input_ids.dtype != torch.int64:
+            input_ids = input_ids.to(torch.int64)  # nn.Embedding takes IntTensor or LongTensor; the kernels index with int64
         ref = input_ids if input_ids is not None else inputs_embeds
         if not ref.is_cuda:
             raise RuntimeError("cm3p_amd runs on MI355X only: inputs must be CUDA/HIP tensors (no CPU fallback)")

@@ -26,7 +26,7 @@ def layernorm_fwd(x: Tensor, weight: Tensor, eps: float, want_f32: bool, want_bf
     y16 = _empty((rows, H), torch.bfloat16, x) if want_bf16 else None
     mean = _empty((rows,), torch.float32, x) if want_stats else None
     rstd = _empty((rows,), torch.float32, x) if want_stats else None
-    call("cm3p_layernorm_fwd", ptr(x), dt(x), ptr(weight), ptr(y32), ptr(y16), ptr(mean), ptr(rstd), rows, H, eps, stream())
+    call("cm3p_layernorm_fwd", ptr(x), dt(x), ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), rows, H, eps, stream())
     return y32, y16, mean, rstd
 
 
@@ -39,7 +39,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, weight: Tensor, mean: Tensor, rstd: Ten
     nblk = query("cm3p_layernorm_bwd_blocks", rows)
     part = _empty((nblk, H), torch.float32, x)
     dw = _empty((H,), torch.float32, x)
-    call("cm3p_layernorm_bwd", ptr(dy), dt(dy), ptr(x), ptr(weight), ptr(mean), ptr(rstd), ptr(dres), ptr(dx32), ptr(dx16),
+    call("cm3p_layernorm_bwd", ptr(dy), dt(dy), ptr(x), ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(dres), ptr(dx32), ptr(dx16),
          ptr(part), ptr(dw), rows, H, stream())
     return dx32, dx16, dw
 
@@ -52,8 +52,8 @@ def embed_ln_fwd(ids: Tensor, table: Tensor, weight: Tensor, eps: float, slot: O
     y16 = _empty((T, H), torch.bfloat16, table) if want_bf16 else None
     mean = _empty((T,), torch.float32, table)
     rstd = _empty((T,), torch.float32, table)
-    call("cm3p_embed_ln_fwd", ptr(ids), ptr(table), dt(table), ptr(slot), ptr(override), dt(override) if override is not None else F32,
-         ptr(weight), ptr(y32), ptr(y16), ptr(mean), ptr(rstd), T, H, eps, stream())
+    call("cm3p_embed_ln_fwd", ptr(ids, torch.int64), ptr(table), dt(table), ptr(slot, torch.int32), ptr(override), dt(override) if override is not None else F32,
+         ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), T, H, eps, stream())
     return y32, y16, mean, rstd
 
 
@@ -66,8 +66,8 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
     nblk = query("cm3p_layernorm_bwd_blocks", T)
     part = _empty((nblk, H), torch.float32, table)
     dw = _empty((H,), torch.float32, table)
-    call("cm3p_embed_ln_bwd", ptr(dy), ptr(ids), ptr(table), dt(table), ptr(slot), ptr(override),
-         dt(override) if override is not None else F32, ptr(weight), ptr(mean), ptr(rstd), ptr(d_table), ptr(d_ovr), ptr(part), ptr(dw),
+    call("cm3p_embed_ln_bwd", ptr(dy), ptr(ids, torch.int64), ptr(table), dt(table), ptr(slot, torch.int32), ptr(override),
+         dt(override) if override is not None else F32, ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(d_table), ptr(d_ovr), ptr(part), ptr(dw),
          T, H, padding_idx, stream())
     return d_table, d_ovr, dw
 
@@ -76,7 +76,7 @@ def audio_slots(ids: Tensor, audio_token_id: int):
     T = ids.numel()
     slot = torch.empty((T,), dtype=torch.int32, device=ids.device)
     count = torch.empty((1,), dtype=torch.int32, device=ids.device)
-    call("cm3p_audio_slots", ptr(ids), T, audio_token_id, ptr(slot), ptr(count), stream())
+    call("cm3p_audio_slots", ptr(ids, torch.int64), T, audio_token_id, ptr(slot, torch.int32), ptr(count), stream())
     return slot, count
 
 
@@ -117,7 +117,7 @@ def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_
     T, Kd = x.shape
     N = w.shape[0]
     out = _empty((T, N), torch.bfloat16, x)
-    call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos), ptr(sin), S, int(per_batch), 2 * N // 3, stream(),
+    call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos, torch.float32), ptr(sin, torch.float32), S, int(per_batch), 2 * N // 3, stream(),
          tag=("gemm256_kernel" if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
          work=2.0 * T * N * Kd)
     return out
@@ -156,12 +156,12 @@ def rope_table(position_ids: Tensor, inv_freq: Tensor):
     half = inv_freq.numel()
     cos = torch.empty((n, half), dtype=torch.float32, device=inv_freq.device)
     sin = torch.empty((n, half), dtype=torch.float32, device=inv_freq.device)
-    call("cm3p_rope_table", ptr(position_ids), n, ptr(inv_freq), half, ptr(cos), ptr(sin), stream())
+    call("cm3p_rope_table", ptr(position_ids, torch.int64), n, ptr(inv_freq, torch.float32), half, ptr(cos, torch.float32), ptr(sin, torch.float32), stream())
     return cos, sin
 
 
 def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, per_batch: bool, inverse: bool = False):
-    call("cm3p_rope_apply", ptr(qkv), ptr(cos), ptr(sin), B, S, nh, S if per_batch else 0, int(inverse), stream())
+    call("cm3p_rope_apply", ptr(qkv), ptr(cos, torch.float32), ptr(sin, torch.float32), B, S, nh, S if per_batch else 0, int(inverse), stream())
     return qkv
 
 
@@ -169,7 +169,7 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
     out = torch.empty((B * S, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     keys = S if window < 0 else min(S, 2 * window + 1)
-    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse), ptr(key_mask), B, S, nh, window, scale, stream(),
+    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, window, scale, stream(),
          tag="attn_fwd_kernel" + ("<global>" if window < 0 else "<local>"), work=4.0 * B * nh * S * keys * 64)
     return out, lse
 
@@ -181,8 +181,8 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
-    call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(key_mask), B, S, nh, window, scale,
-         ptr(cos), ptr(sin), S if per_batch else 0, stream(), tag="attn_bwd(dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
+    call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh, window, scale,
+         ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stream(), tag="attn_bwd(dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
     return dqkv
 
 
@@ -191,7 +191,7 @@ def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window
     total = qkv.shape[0]
     out = torch.empty((total, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((nh, total), dtype=torch.float32, device=qkv.device)
-    call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse), ptr(cu), B, max_s, total, nh, window, scale, stream(),
+    call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(cu, torch.int32), B, max_s, total, nh, window, scale, stream(),
          tag="attn_fwd_kernel" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
     return out, lse
 
@@ -202,22 +202,22 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
-    call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(cu), B, max_s, qkv.shape[0], nh,
-         window, scale, ptr(cos), ptr(sin), stream(), tag="attn_bwd(dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+    call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s, qkv.shape[0], nh,
+         window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stream(), tag="attn_bwd(dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
     return dqkv
 
 
 def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
     """src [R, H] fp32, idx int64 [n] -> [n, H] (the row selection of _unpad_cm3p_input)."""
     out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
-    call("cm3p_gather_rows_f32", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], stream())
+    call("cm3p_gather_rows_f32", ptr(src), ptr(idx, torch.int64), ptr(out), idx.numel(), src.shape[1], stream())
     return out
 
 
 def scatter_rows(src: Tensor, idx: Tensor, rows: int) -> Tensor:
     """src [n, H] fp32 -> [rows, H] with row idx[i] = src[i] and zeros elsewhere (_pad_cm3p_output)."""
     out = torch.zeros((rows, src.shape[1]), dtype=torch.float32, device=src.device)
-    call("cm3p_scatter_rows_f32", ptr(src), ptr(idx), ptr(out), idx.numel(), src.shape[1], stream())
+    call("cm3p_scatter_rows_f32", ptr(src), ptr(idx, torch.int64), ptr(out), idx.numel(), src.shape[1], stream())
     return out
 
 
@@ -284,14 +284,14 @@ def pool_fwd(h: Tensor, mask: Optional[Tensor], Bn: int, S: int, cls: bool):
     pooled = torch.empty((Bn, H), dtype=torch.float32, device=h.device)
     count = torch.empty((Bn,), dtype=torch.float32, device=h.device)
     part = None if cls else torch.empty((Bn, query("cm3p_pool_chunks", S), H), dtype=torch.float32, device=h.device)
-    call("cm3p_pool_fwd", ptr(h), ptr(mask), ptr(pooled), ptr(part), ptr(count), Bn, S, H, int(cls), stream())
+    call("cm3p_pool_fwd", ptr(h), ptr(mask, torch.int64), ptr(pooled), ptr(part), ptr(count), Bn, S, H, int(cls), stream())
     return pooled, count
 
 
 def pool_bwd(dpooled: Tensor, mask: Optional[Tensor], count: Tensor, Bn: int, S: int, cls: bool) -> Tensor:
     H = dpooled.shape[-1]
     dh = torch.empty((Bn * S, H), dtype=torch.float32, device=dpooled.device)
-    call("cm3p_pool_bwd", ptr(dpooled), ptr(mask), ptr(count), ptr(dh), Bn, S, H, int(cls), stream())
+    call("cm3p_pool_bwd", ptr(dpooled), ptr(mask, torch.int64), ptr(count), ptr(dh), Bn, S, H, int(cls), stream())
     return dh
 
 
@@ -322,7 +322,7 @@ def l2norm_bwd(dy: Tensor, y: Tensor, norm: Tensor) -> Tensor:
 def cross_entropy(logits: Tensor, rows: int, cols: int, row_stride: int, col_stride: int, target: Tensor,
                   row_offset: Optional[Tensor], grad_scale: float, dlogits: Optional[Tensor]) -> Tensor:
     loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
-    call("cm3p_cross_entropy", ptr(logits), rows, cols, row_stride, col_stride, ptr(row_offset), ptr(target), grad_scale,
+    call("cm3p_cross_entropy", ptr(logits, torch.float32), rows, cols, row_stride, col_stride, ptr(row_offset, torch.int64), ptr(target, torch.int64), grad_scale,
          ptr(loss_rows), ptr(dlogits), stream())
     return loss_rows
 
@@ -332,7 +332,7 @@ def cross_entropy_masked(logits: Tensor, cols: int, target: Tensor, ignore_index
     rows, pitch = logits.shape
     loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits) if want_grad else None
-    call("cm3p_cross_entropy_masked", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, grad_scale, ptr(inv_count),
+    call("cm3p_cross_entropy_masked", ptr(logits, torch.float32), rows, cols, pitch, ptr(target, torch.int64), ignore_index, grad_scale, ptr(inv_count, torch.float32),
          ptr(loss_rows), ptr(dlogits), stream())
     return loss_rows, dlogits
 
@@ -342,7 +342,7 @@ def ce_masked_stats(logits: Tensor, cols: int, target: Tensor, ignore_index: int
     rows, pitch = logits.shape
     loss_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
     lse_rows = torch.empty((rows,), dtype=torch.float32, device=logits.device)
-    call("cm3p_ce_masked_stats", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, ptr(loss_rows), ptr(lse_rows), stream())
+    call("cm3p_ce_masked_stats", ptr(logits, torch.float32), rows, cols, pitch, ptr(target, torch.int64), ignore_index, ptr(loss_rows), ptr(lse_rows, torch.float32), stream())
     return loss_rows, lse_rows
 
 
@@ -352,14 +352,14 @@ def ce_masked_dlogits_bf16(logits: Tensor, cols: int, target: Tensor, ignore_ind
     dl = torch.empty((rows, pitch), dtype=torch.bfloat16, device=logits.device)
     part = torch.empty((query("cm3p_ce_masked_dlogits_blocks", rows), pitch), dtype=torch.float32, device=logits.device)
     colsum = torch.empty((pitch,), dtype=torch.float32, device=logits.device)
-    call("cm3p_ce_masked_dlogits_bf16", ptr(logits), rows, cols, pitch, ptr(target), ignore_index, ptr(lse_rows), ptr(scale_a), ptr(scale_b),
+    call("cm3p_ce_masked_dlogits_bf16", ptr(logits, torch.float32), rows, cols, pitch, ptr(target, torch.int64), ignore_index, ptr(lse_rows, torch.float32), ptr(scale_a, torch.float32), ptr(scale_b, torch.float32),
          ptr(dl), ptr(part), ptr(colsum), stream())
     return dl, colsum
 
 
 def inv_valid_count(target: Tensor, ignore_index: int) -> Tensor:
     out = torch.empty((1,), dtype=torch.float32, device=target.device)
-    call("cm3p_inv_valid_count", ptr(target), target.numel(), ignore_index, ptr(out), stream())
+    call("cm3p_inv_valid_count", ptr(target, torch.int64), target.numel(), ignore_index, ptr(out), stream())
     return out
 
 
@@ -387,7 +387,7 @@ def pointwise_loss(x: Tensor, y: Tensor, kind: int):
 def first_zero_index(classes: Tensor) -> Tensor:
     B, V = classes.shape
     idx = torch.empty((B,), dtype=torch.int64, device=classes.device)
-    call("cm3p_first_zero_index", ptr(classes), B, V, ptr(idx), stream())
+    call("cm3p_first_zero_index", ptr(classes, torch.int64), B, V, ptr(idx, torch.int64), stream())
     return idx
 
 

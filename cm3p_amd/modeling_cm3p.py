@@ -486,7 +486,7 @@ class CM3PBeatmapTransformer(nn.Module):
             if input_features is not None:
                 audio_out = self.audio_encoder(input_features)
                 rows = audio_out.audio_embeds
-                slot, count = K.audio_slots(input_ids.contiguous().view(-1), int(self.config.audio_token_id))
+                slot, count = K.audio_slots(input_ids.contiguous().view(-1).to(torch.int64), int(self.config.audio_token_id))
                 # the reference's masked assignment raises on a count mismatch (ref:cm3p/modeling_cm3p.py:603-605)
                 n = int(count.item())
                 if n != rows.shape[0]:

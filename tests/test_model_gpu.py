@@ -465,6 +465,43 @@ def test_mlm_logits_used_outside_the_loss_still_get_their_gradient():
         assert _rel(both[k], want) <= 2e-2, (k, _rel(both[k], want))
 
 
+def test_input_dtype_and_layout_variants_give_the_reference_case_result():
+    """What callers actually pass: bool / float attention masks, int32 token ids (nn.Embedding takes IntTensor), non-contiguous
+    id tensors, unpadded execution with a bool mask.  All must equal the int64 case bit for bit - and none may reach a kernel
+    with a dtype it does not read (int32 ids read as int64 walk off the embedding table: a GPU fault, found in r01)."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    ins = _inputs(blob)
+    model = _build(name)
+    ref = model(**ins).loss
+    variants = {
+        "bool masks": dict(attention_mask=ins["attention_mask"].bool(), metadata_attention_mask=ins["metadata_attention_mask"].bool()),
+        "float masks": dict(attention_mask=ins["attention_mask"].float(), metadata_attention_mask=ins["metadata_attention_mask"].float()),
+        "int32 ids": dict(input_ids=ins["input_ids"].int(), metadata_ids=ins["metadata_ids"].int()),
+        "non-contiguous ids": dict(input_ids=ins["input_ids"].t().contiguous().t()),
+    }
+    for what, kw in variants.items():
+        out = model(**{**ins, **kw})
+        out.loss.backward()
+        assert torch.equal(out.loss, ref), what
+    model.unpad_inputs = True
+    out = model(**{**ins, "attention_mask": ins["attention_mask"].bool()})
+    assert abs(out.loss.item() - ref.item()) <= 1e-5, "unpadded, bool mask"
+
+
+def test_kernel_wrappers_refuse_a_dtype_the_kernel_does_not_read():
+    from cm3p_amd import kernels as K
+
+    pos = torch.arange(8, device=DEV, dtype=torch.int32)
+    inv = torch.ones(32, device=DEV)
+    with pytest.raises(TypeError):
+        K.rope_table(pos, inv)
+    with pytest.raises(TypeError):
+        K.gather_rows(torch.zeros(4, 8, device=DEV), torch.zeros(2, device=DEV, dtype=torch.int32))
+    with pytest.raises(TypeError):
+        K.inv_valid_count(torch.zeros(8, device=DEV, dtype=torch.int32), -100)
+
+
 def test_gradient_checkpointing_recomputes_bit_identically():
     """model.gradient_checkpointing_enable() (ref:cm3p/modeling_cm3p.py:257 supports_gradient_checkpointing): the stack keeps one
     tensor per layer and recomputes the rest with the same deterministic kernels - losses and gradients are bit-identical."""
