@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -27,8 +27,8 @@ SIGNATURES = {
     "cm3p_layernorm_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
     "cm3p_layernorm_bwd_blocks": [_L],
     "cm3p_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
-    "cm3p_embed_ln_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P],
-    "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _P],
+    "cm3p_embed_ln_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _L, _P],
+    "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
     "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _P],

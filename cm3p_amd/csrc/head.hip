@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     se = block_reduce(se, red, false);
     const float lse = mx + logf(se);
     const int64_t t = target[r];
-    if (threadIdx.x == 0) loss_rows[r] = lse - x[t * col_stride];
+    if (threadIdx.x == 0) loss_rows[r] = (uint64_t)t < (uint64_t)cols ? lse - x[t * col_stride] : 0.f;  // (a target outside the row is never read)
     if (dlogits) {
         float* d = dlogits + base;
         for (int c = threadIdx.x; c < cols; c += 256) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void cross_entropy_masked_kernel(const float* 
     const float* x = logits + (int64_t)r * row_stride;
     float* d = dlogits ? dlogits + (int64_t)r * row_stride : nullptr;
     const int64_t t = target[r];
-    if (t == ignore_index) {  // block-uniform
+    if (t == ignore_index || (uint64_t)t >= (uint64_t)cols) {  // block-uniform; a label outside [0, cols) is ignored too, never read
         if (threadIdx.x == 0) loss_rows[r] = 0.f;
         if (d)
             for (int c = threadIdx.x; c < row_stride; c += 256) d[c] = 0.f;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ce_masked_stats_kernel(const float* __res
     __shared__ float red[4];
     const int r = blockIdx.x;
     const int64_t t = target[r];
-    if (t == ignore_index) {  // block-uniform
+    if (t == ignore_index || (uint64_t)t >= (uint64_t)cols) {  // block-uniform; a label outside [0, cols) is ignored too, never read
         if (threadIdx.x == 0) {
             loss_rows[r] = 0.f;
             lse_rows[r] = 0.f;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void ce_masked_dlogits_kernel(const float* __r
     for (int64_t r = r0; r < r1; ++r) {
         const int64_t t = tg[r - r0];  // workgroup-uniform
         uint16_t* drow = dl + r * pitch;
-        if (t == ignore_index) {
+        if (t == ignore_index || (uint64_t)t >= (uint64_t)cols) {
 #pragma unroll
             for (int q = 0; q < kDlQuads; ++q) {
                 const int c4 = qbase + threadIdx.x + 256 * q;

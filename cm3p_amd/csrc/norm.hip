@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
 // ref:cm3p/modeling_cm3p.py:603-605), else table[ids[t]].
 template <bool TAB_BF16, bool OVR_BF16, int NC>
 __device__ __forceinline__ void load_embed_row(RowRegs<NC>& r, const int64_t* ids, const void* table, const int32_t* slot,
-                                               const void* ovr, int64_t t, int H, int lane) {
+                                               const void* ovr, int64_t t, int H, int lane, int64_t vocab) {
     const int s = slot ? slot[t] : -1;
     if (s >= 0) {
         const void* src = OVR_BF16 ? (const void*)(static_cast<const uint16_t*>(ovr) + (int64_t)s * H)
@@ -200,6 +200,11 @@ __device__ __forceinline__ void load_embed_row(RowRegs<NC>& r, const int64_t* id
         load_row<OVR_BF16, NC>(r, src, H, lane);
     } else {
         const int64_t id = ids[t];
+        if ((uint64_t)id >= (uint64_t)vocab) {  // nn.Embedding raises a device-side assert here; a kernel must not fault: zero row
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
         const void* src = TAB_BF16 ? (const void*)(static_cast<const uint16_t*>(table) + id * H)
                                    : (const void*)(static_cast<const float*>(table) + id * H);
         load_row<TAB_BF16, NC>(r, src, H, lane);
@@ -211,13 +216,13 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                            const int32_t* __restrict__ slot, const void* __restrict__ ovr,
                                                            const float* __restrict__ w, float* __restrict__ y32,
                                                            uint16_t* __restrict__ y16, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out, int64_t T, int H, float eps) {
+                                                           float* __restrict__ rstd_out, int64_t T, int H, float eps, int64_t vocab) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t t = wave; t < T; t += nwaves) {
         RowRegs<NC> r;
-        load_embed_row<TAB_BF16, OVR_BF16, NC>(r, ids, table, slot, ovr, t, H, lane);
+        load_embed_row<TAB_BF16, OVR_BF16, NC>(r, ids, table, slot, ovr, t, H, lane, vocab);
         float mean, rstd;
         row_stats(r, H, lane, eps, mean, rstd);
         store_norm(r, w, mean, rstd, y32 ? y32 + t * H : nullptr, y16 ? y16 + t * H : nullptr, H, lane);
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            float* __restrict__ d_table, float* __restrict__ d_ovr,
                                                            float* __restrict__ dw_partial, int64_t T, int H,
-                                                           int64_t padding_idx) {
+                                                           int64_t padding_idx, int64_t vocab) {
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
     for (int c = 0; c < NC; ++c) dw.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int64_t t = wave; t < T; t += nwaves) {
         RowRegs<NC> xr, gr;
-        load_embed_row<TAB_BF16, OVR_BF16, NC>(xr, ids, table, slot, ovr, t, H, lane);
+        load_embed_row<TAB_BF16, OVR_BF16, NC>(xr, ids, table, slot, ovr, t, H, lane, vocab);
         load_row<false, NC>(gr, dy + t * H, H, lane);
         const float mean = mean_in[t], rstd = rstd_in[t];
         float s1 = 0.f, s2 = 0.f;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
         // nn.Embedding(padding_idx=pad_token_id) gives the padding row no gradient (TF:...modeling_modernbert.py:60)
         const int64_t id = ids[t];
         float* dst = s >= 0 ? (d_ovr ? d_ovr + (int64_t)s * H : nullptr)
-                            : ((d_table && id != padding_idx) ? d_table + id * H : nullptr);
+                            : ((d_table && id != padding_idx && (uint64_t)id < (uint64_t)vocab) ? d_table + id * H : nullptr);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int col = c * 256 + lane * 4;
@@ -398,15 +403,15 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
 
 int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, const int32_t* slot, const void* override_rows,
                       int override_dtype, const float* weight, float* y_f32, void* y_bf16, float* mean, float* rstd, int64_t T,
-                      int H, float eps, void* stream) {
-    CM3P_REQUIRE(ids && table && weight && mean && rstd && (y_f32 || y_bf16) && T >= 0 && H > 0 && H % 4 == 0 && H <= 2048);
+                      int H, float eps, int64_t vocab, void* stream) {
+    CM3P_REQUIRE(ids && table && weight && mean && rstd && (y_f32 || y_bf16) && T >= 0 && H > 0 && H % 4 == 0 && H <= 2048 && vocab > 0);
     CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
     if (T == 0) return CM3P_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = ln_grid(T);
     const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
 #define CM3P_EMB_FWD_NC(NC) \
-    embed_ln_fwd_kernel<TB_, OB_, NC><<<grid, 256, 0, s>>>(ids, table, slot, override_rows, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, T, H, eps);
+    embed_ln_fwd_kernel<TB_, OB_, NC><<<grid, 256, 0, s>>>(ids, table, slot, override_rows, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, T, H, eps, vocab);
 #define CM3P_EMB_FWD(TB, OB)               \
     do {                                   \
         constexpr bool TB_ = TB, OB_ = OB; \
@@ -425,7 +430,7 @@ int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, co
 int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
                       const void* override_rows, int override_dtype, const float* weight, const float* mean, const float* rstd,
                       float* d_table, float* d_override, float* dw_partial, float* dw, int64_t T, int H, int64_t padding_idx,
-                      void* stream) {
+                      int64_t vocab, void* stream) {
     CM3P_REQUIRE(dy && ids && table && weight && mean && rstd && dw_partial && dw && T > 0 && H > 0 && H % 4 == 0 && H <= 2048);
     CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -434,7 +439,7 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
     const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
 #define CM3P_EMB_BWD_NC(NC)                                                                                              \
     embed_ln_bwd_kernel<TB_, OB_, NC><<<grid, 256, lds, s>>>(dy, ids, table, slot, override_rows, weight, mean, rstd, d_table, \
-                                                             d_override, dw_partial, T, H, padding_idx);
+                                                             d_override, dw_partial, T, H, padding_idx, vocab);
 #define CM3P_EMB_BWD(TB, OB)               \
     do {                                   \
         constexpr bool TB_ = TB, OB_ = OB; \

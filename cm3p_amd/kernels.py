@@ -53,7 +53,7 @@ def embed_ln_fwd(ids: Tensor, table: Tensor, weight: Tensor, eps: float, slot: O
     mean = _empty((T,), torch.float32, table)
     rstd = _empty((T,), torch.float32, table)
     call("cm3p_embed_ln_fwd", ptr(ids, torch.int64), ptr(table), dt(table), ptr(slot, torch.int32), ptr(override), dt(override) if override is not None else F32,
-         ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), T, H, eps, stream())
+         ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), T, H, eps, table.shape[0], stream())
     return y32, y16, mean, rstd
 
 
@@ -68,7 +68,7 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
     dw = _empty((H,), torch.float32, table)
     call("cm3p_embed_ln_bwd", ptr(dy), ptr(ids, torch.int64), ptr(table), dt(table), ptr(slot, torch.int32), ptr(override),
          dt(override) if override is not None else F32, ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(d_table), ptr(d_ovr), ptr(part), ptr(dw),
-         T, H, padding_idx, stream())
+         T, H, padding_idx, V, stream())
     return d_table, d_ovr, dw
 
 

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 6
+#define CM3P_ABI_VERSION 7
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -57,17 +57,18 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
  * Replaces ModernBertEmbeddings.forward (TF:...modeling_modernbert.py:64-71) fed by
  * CM3PBeatmapTransformer.forward's `inputs_embeds[input_ids == audio_token_id] = audio_embeds`
  * (ref:cm3p/modeling_cm3p.py:592,603-605).  slot[t] >= 0 selects override_rows[slot[t]] instead of table[ids[t]];
- * slot / override_rows may both be NULL. */
+ * slot / override_rows may both be NULL.  vocab = rows of `table`: an id outside [0, vocab) reads as a zero row and receives no
+ * gradient (nn.Embedding raises a device-side assert there; these kernels must not fault). */
 int cm3p_embed_ln_fwd(const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
                       const void* override_rows, int override_dtype, const float* weight, float* y_f32, void* y_bf16,
-                      float* mean, float* rstd, int64_t T, int H, float eps, void* stream);
+                      float* mean, float* rstd, int64_t T, int H, float eps, int64_t vocab, void* stream);
 
 /* Backward: d_table[ids[t]] += row gradient (fp32 atomics; the caller zeroes d_table; row `padding_idx` gets none,
  * as nn.Embedding(padding_idx=...) does), d_override[slot[t]] = row gradient.  Either may be NULL. */
 int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, int table_dtype, const int32_t* slot,
                       const void* override_rows, int override_dtype, const float* weight, const float* mean,
                       const float* rstd, float* d_table, float* d_override, float* dw_partial, float* dw, int64_t T, int H,
-                      int64_t padding_idx, void* stream);
+                      int64_t padding_idx, int64_t vocab, void* stream);
 
 /* slot[t] = rank of token t among the tokens equal to audio_token_id, in row-major (b, s) order, else -1;
  * count[0] = how many there are.  The integer side of ref:cm3p/modeling_cm3p.py:604-605 (bit-exact). */

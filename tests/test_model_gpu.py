@@ -489,6 +489,31 @@ def test_input_dtype_and_layout_variants_give_the_reference_case_result():
     assert abs(out.loss.item() - ref.item()) <= 1e-5, "unpadded, bool mask"
 
 
+def test_out_of_range_token_ids_and_labels_do_not_fault():
+    """nn.Embedding / cross_entropy raise a device-side assert for ids or labels outside the vocabulary; a hand-written kernel must
+    not turn that caller bug into an out-of-bounds access: such ids read as a zero row and get no gradient, such labels are
+    ignored.  Everything stays finite and the rows of well-formed samples are untouched."""
+    name = "d64_mlm"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    ins = _inputs(blob)
+    model = _build(name)
+    ref = model(**ins)
+    V = model.config.beatmap_config.vocab_size
+    bad = {k: v.clone() for k, v in ins.items()}
+    bad["input_ids"][0, 3] = V + 1000          # far outside the table
+    bad["input_ids"][0, 5] = -7
+    bad["labels"][0, 3] = V + 5
+    out = model(**bad)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.loss) and torch.isfinite(out.logits).all()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+    # samples 1.. of the batch never saw the bad ids: their embeddings are unchanged
+    assert torch.equal(out.beatmap_embeds[1:], ref.beatmap_embeds[1:])
+
+
 def test_kernel_wrappers_refuse_a_dtype_the_kernel_does_not_read():
     from cm3p_amd import kernels as K
 
