@@ -23,9 +23,11 @@ class _ConvGeluFn(torch.autograd.Function):
         Co, Ci, _ = W.shape
         xd = x.detach().contiguous()
         if token_major:
-            B, T_in, _ = xd.shape
+            B, T_in, C_in = xd.shape
         else:
-            B, _, T_in = xd.shape
+            B, C_in, T_in = xd.shape
+        if C_in != Ci:
+            raise ValueError(f"Conv1d expects {Ci} input channels, got {C_in}")  # (nn.Conv1d raises too; the kernel would read out of bounds)
             if xd.dtype != torch.float32:
                 xd = xd.float()
         patches, T_out = K.im2col_k3(xd, token_major, B, Ci, T_in, stride)

@@ -279,6 +279,8 @@ class _MLMHeadLossFn(torch.autograd.Function):
         logits, ctx.pack, ctx.meta = _mlm_head_forward(h, Wd, bd, norm_w, Wdec, bdec, eps)
         V = Wdec.shape[0]
         lab = labels.reshape(-1).contiguous().to(torch.int64)
+        if lab.numel() != logits.shape[0]:
+            raise ValueError(f"labels have {lab.numel()} entries, the logits {logits.shape[0]} rows")
         if num_items is None:
             inv = K.inv_valid_count(lab, -100)
         else:
@@ -884,6 +886,9 @@ class CM3PForBeatmapClassification(CM3PPreTrainedModel):
                     self.config.problem_type = "single_label_classification"
                 else:
                     self.config.problem_type = "multi_label_classification"
+            want = logits.shape[0] if self.config.problem_type == "single_label_classification" else logits.numel()
+            if labels.numel() != want:  # (the torch losses raise on a size mismatch; the kernels would read past the labels)
+                raise ValueError(f"labels have {labels.numel()} entries, expected {want}")
             if self.config.problem_type == "regression":
                 loss = _PointwiseLossFn.apply(logits.reshape(-1), labels.reshape(-1), 0)
             elif self.config.problem_type == "single_label_classification":
