@@ -85,7 +85,11 @@ def _f32(w: Tensor) -> Tensor:
 def _bf16_weight(w: Tensor) -> Tensor:
     """bf16 GEMM operand of a master weight (what autocast's per-call cast produces)."""
     w = w.detach()
-    return w if w.dtype == torch.bfloat16 else K.cast_bf16(w.contiguous())
+    if w.dtype == torch.bfloat16:
+        return w
+    if w.dtype != torch.float32:  # fp16 / fp64 checkpoints: widen first (dtype plumbing; the cast kernel reads fp32)
+        w = w.float()
+    return K.cast_bf16(w.contiguous())
 
 
 class _Geometry:

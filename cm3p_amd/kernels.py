@@ -139,7 +139,7 @@ def linear_wgrad(dy: Tensor, x: Tensor) -> Tensor:
 
 def cast_bf16(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    call("cm3p_cast_f32_bf16", ptr(x), ptr(y), x.numel(), stream())
+    call("cm3p_cast_f32_bf16", ptr(x, torch.float32), ptr(y), x.numel(), stream())
     return y
 
 
