@@ -12,10 +12,18 @@ batch 32 per GPU); for N > 1 the batch is sharded over ranks (weak scaling), emb
 in-batch negatives and gradients are all-reduced (configs[2], "C3").  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (largest share of step time), timed live with HIP events on the launching stream
-                over the timed steps: algorithmic FLOPs per launch / average launch duration vs the dense bf16 MFMA peak.
+  roofline      the dominant kernel = the C-ABI tag with the largest share of one fully bracketed step, no filter (every tag
+                is ONE kernel, spelled like its rocprofv3 row), timed live with HIP events on the launching stream over the
+                timed steps: algorithmic FLOPs per launch (SURVEY.md section 8d counting: attention backward = 2 x forward,
+                recomputed scores not credited) / average launch duration vs the dense bf16 MFMA peak.  `traffic` and
+                `mfma_busy` come from the committed rocprofv3 PMC passes of this same command (files named in the object).
   cpu_baseline  the CPU oracle (oracle/cm3p_oracle.py: the reference's fp32 sdpa path restated) timed on the host's cores on
-                a bounded sample of the same workload, rank 0 at N = 1 only.
+                a bounded sample of the same workload (B = 2 at the real sequence lengths, 1 warm-up +
+                2 timed iterations), rank 0 at N = 1 only.
+  secondary     N = 1 only: BASELINE configs[3] ("C4": beatmap seq 8192, batch 16) timed for 3 steps after the judged region,
+                so the north-star target (fraction of bf16 MFMA peak on fwd+bwd at seq 8192) is observed by the same run.
+  comm          N > 1 only: the step re-timed without the gradient all-reduce (DDP no_sync) and without the embedding
+                all-gather -> exposed_allreduce_ms / exposed_allgather_ms per step (max over ranks).
 """
 from __future__ import annotations
 
@@ -32,6 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0  # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured with a float4 copy)
 
 WORKLOADS = {
     # name: (per-GPU batch, beatmap seq, metadata seq, audio frames or None)
@@ -90,15 +99,21 @@ def make_batch(config, w, rank: int, device):
     return batch
 
 
-def pmc_traffic(workload: str, tag: str):
-    """HBM bytes per launch of `tag` from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic_<workload>.json, written by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+def pmc_value(kind: str, workload: str, tag: str):
+    """-> (value, file) from the committed rocprofv3 PMC passes of this same command, or (None, None).
+    kind "traffic": HBM bytes per launch of `tag` (profiles/traffic_<workload>.json, written by tools/pmc_traffic.py: FETCH_SIZE
+    and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    kind "mfma_util": matrix-pipe busy fraction (profiles/mfma_util_<workload>.json, tools/pmc_mfma.py)."""
+    rel = os.path.join("profiles", f"{kind}_{workload}.json")
     try:
-        return json.load(open(path)).get(tag)
+        d = json.load(open(os.path.join(ROOT, rel)))
     except Exception:
-        return None
+        return None, None
+    for key in (tag, tag.split("<")[0]):  # exact tag first, then the kernel name without its <global>/<local> suffix
+        if key in d:
+            v = d[key]
+            return ((v.get("busy_frac", v.get("mfma_util"))) if isinstance(v, dict) else v), rel
+    return None, rel
 
 
 def host_cores() -> int:
@@ -119,7 +134,9 @@ def host_cores() -> int:
 
 
 def cpu_baseline(workload: str) -> dict:
-    """Time the CPU oracle on a bounded sample: one sequence pair of the same lengths, fp32, all host cores."""
+    """Time the CPU oracle on a bounded sample: B = 2 at the workload's real sequence lengths, fp32
+    sdpa path, all host cores, 1 warm-up + 2 timed forward+backward iterations (B = 1 and 1 timed iteration for the 8192-token
+    workload, whose iteration is ~3x longer)."""
     from oracle import cm3p_oracle as O
 
     w = WORKLOADS[workload]
@@ -128,21 +145,31 @@ def cpu_baseline(workload: str) -> dict:
     print(f"[bench] cpu_baseline: oracle on {cores} host threads ...", file=sys.stderr, flush=True)
     cfg = {}
     sd = {k: v.requires_grad_(v.dtype.is_floating_point) for k, v in O.init_state_dict(cfg, seed=0, with_audio=bool(w["audio_T"])).items()}
-    Bc = 1
+    Bc, iters = (2, 2) if w["S"] <= 4096 else (1, 1)
     batch = O.synthetic_batch(cfg, Bc, w["S"], w["L"], seed=1234, audio_T=w["audio_T"])
-    # thread-pool warm-up on a tiny shape, then ONE timed forward + backward
-    tiny = O.synthetic_batch(cfg, 1, 64, 16, seed=1)
-    O.forward(sd, cfg, **tiny)["loss"].backward()
-    t0 = time.perf_counter()
-    loss = O.forward(sd, cfg, **batch)["loss"]
-    print(f"[bench] cpu_baseline: forward {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    print(f"[bench] cpu_baseline: forward+backward {dt:.1f} s", file=sys.stderr, flush=True)
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        O.forward(sd, cfg, **batch)["loss"].backward()
+        return time.perf_counter() - t0
+
+    warm = one()
+    print(f"[bench] cpu_baseline: warm-up iteration {warm:.1f} s", file=sys.stderr, flush=True)
+    times = []
+    for _ in range(iters):
+        times.append(one())
+        print(f"[bench] cpu_baseline: timed iteration {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    dt = sum(times) / len(times)
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        cpu = "unknown"
     return {
-        "value": Bc / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-        "sample": f"1 step of B={Bc} at the same sequence lengths (beatmap {w['S']}, metadata {w['L']}), fp32 sdpa path, "
-                  f"{dt:.1f} s; the full B={w['B']} step does not fit host memory",
+        "value": Bc / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu": cpu,
+        "sample": f"forward+backward of B={Bc} at the same sequence lengths (beatmap {w['S']}, metadata {w['L']}), fp32 sdpa path, "
+                  f"1 warm-up ({warm:.1f} s) + {iters} timed iteration(s) (mean {dt:.1f} s); the full B={w['B']} step does not fit host memory",
     }
 
 
@@ -190,6 +217,9 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separately reported Muon optimizer-step timing")
     ap.add_argument("--padded", action="store_true", help="not the judged configuration: right-padded rows, valid length ~ U{S/2..S}")
     ap.add_argument("--unpad", action="store_true", help="with --padded: run the beatmap tower on the valid tokens only (unpadded execution)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C4 (seq 8192) line reported next to the judged C2 number at N = 1")
+    ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
+                    help="N > 1: DDP communication hook (bf16 halves the 545 MB fp32 gradient all-reduce; off in the judged run)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -238,6 +268,10 @@ def main():
         model.gather_negatives = True
         step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], gradient_as_bucket_view=True,
                                                                bucket_cap_mb=32)  # per-layer autograd nodes: buckets fill (and reduce) while backward runs
+        if args.grad_compress == "bf16":
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+            step_model.register_comm_hook(None, default_hooks.bf16_compress_hook)
     batch = make_batch(config, w, rank, device)
     if args.unpad:
         model.unpad_inputs = True
@@ -268,8 +302,7 @@ def main():
         _lib.profile_begin()
         step()
         prof_all = _lib.profile_end()
-        single = {k: v for k, v in prof_all.items() if k.startswith(("gemm", "attn_fwd"))}
-        dom_tag = max(single.items(), key=lambda kv: kv[1][1])[0]
+        dom_tag = max(prof_all.items(), key=lambda kv: kv[1][1])[0]  # largest share of the step, no filter: every tag is one kernel
     fence()
     if profile:
         _lib.profile_begin(only=dom_tag)
@@ -284,8 +317,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def timed(fn, n):
+        """n calls of fn between fences -> ms per call, max over ranks (outside the judged region)."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n * 1e3
+
     ms_per_step = elapsed / args.steps * 1e3
     pairs_per_s = world * w["B"] * args.steps / elapsed
+    comm = None
+    if world > 1:
+        # SURVEY.md section 8(d) step-time split: the same step without the gradient all-reduce (DDP no_sync), then also without
+        # the embedding all-gather (rank-local negatives); differences = what each collective leaves exposed per step
+        n_comm = max(2, min(args.steps, 5))
+
+        def step_nosync():
+            with step_model.no_sync():
+                step()
+
+        ms_nosync = timed(step_nosync, n_comm)
+        model.gather_negatives = False
+        ms_local = timed(step_nosync, n_comm)
+        model.gather_negatives = True
+        comm = {"ms_per_step": ms_per_step, "ms_per_step_no_allreduce": ms_nosync, "ms_per_step_no_allreduce_no_allgather": ms_local,
+                "exposed_allreduce_ms": ms_per_step - ms_nosync, "exposed_allgather_ms": ms_nosync - ms_local,
+                "gradient_bytes_per_step": sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad),
+                "grad_compress": args.grad_compress, "bucket_cap_mb": 32, "steps_per_leg": n_comm}
     flops = step_flops(config, w)
     result = {
         "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",
@@ -319,16 +384,39 @@ def main():
             # HIP events inside the timed region, on the stream they run on
             tag, (n, ms, work) = dom_tag, prof[dom_tag]
             total_ms = sum(v[1] for v in prof_all.values())  # one fully bracketed (untimed) step
-            achieved = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            hbm_bound = tag in _lib.HBM_BOUND_TAGS  # (their `work` is algorithmic bytes)
+            peak, unit, scale = (HBM_PEAK_GBS, "GB/s", 1e9) if hbm_bound else (BF16_MFMA_PEAK_TFLOPS, "TFLOP/s", 1e12)
+            achieved = work / (ms * 1e-3) / scale if ms > 0 else 0.0
+            traffic, traffic_file = pmc_value("traffic", args.workload, tag)
+            busy, busy_file = pmc_value("mfma_util", args.workload, tag)
             result["roofline"] = {
-                "kernel": tag, "bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, tag),
+                "kernel": tag, "bound": "hbm" if hbm_bound else "mfma", "achieved": achieved, "peak": peak, "unit": unit,
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_file,
+                "mfma_busy": busy, "mfma_busy_source": busy_file,
                 "launches": n, "avg_launch_ms": ms / n, "share_of_kernel_time": (ms / args.steps) / total_ms,
-                "flop_per_launch": work / n,
+                "work_per_launch": work / n,
+                "counting": "SURVEY.md 8(d): matmul FLOPs 2mnk, attention backward = 2 x forward (recomputed scores not credited)",
             }
             result["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])[:12]}
             result["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
+        if comm is not None:
+            result["comm"] = comm
+    if world == 1 and args.workload == "c2" and not args.no_secondary and not args.padded and not args.batch:
+        # BASELINE configs[3] next to the judged number: the north-star target is quoted at seq 8192
+        w4 = dict(WORKLOADS["c4"])
+        del batch
+        torch.cuda.empty_cache()
+        batch = make_batch(config, w4, rank, device)
+        step()
+        ms4 = timed(step, 3)
+        f4 = step_flops(config, w4)
+        result["secondary"] = {"workload": f"c4: {w4['desc']}", "steps": 3, "warmup": 1, "ms_per_step": ms4, "value": w4["B"] / (ms4 * 1e-3),
+                               "unit": "pairs/s", "step_tflops_algorithmic": f4 / 1e12,
+                               "step_mfma_frac": f4 / (ms4 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "target_mfma_frac": 0.40}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not w.get("mlm"):  # (the oracle's timed leg covers the BASELINE workloads)
+            del batch
+            torch.cuda.empty_cache()
             result["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(result), flush=True)
     if world > 1:

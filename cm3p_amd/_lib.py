@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -38,7 +38,7 @@ SIGNATURES = {
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
     "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _P],
+    "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _P],
     "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
     "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],
     "cm3p_gelu_fwd": [_P, _P, _L, _P],
@@ -70,7 +70,7 @@ SIGNATURES = {
     "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
     "cm3p_pointwise_loss": [_P, _P, _P, _P, _L, _I, _P],
     "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P],
-    "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _P],
+    "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P],
     "cm3p_gather_rows_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_gemm_bf16_batched": [_P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _F, _F, _P],
@@ -114,10 +114,15 @@ def _check(rc: int, name: str):
         raise Cm3pHipError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
 
 
+class _DevPtr(int):
+    """A device address that remembers which GPU it lives on (ctypes takes it as the plain integer it is)."""
+
+
 def ptr(t: torch.Tensor | None, dtype: torch.dtype | None = None):
     """Device address of a contiguous GPU tensor.  `dtype`: what the C entry point reads there - a kernel handed int32 token ids
     where it reads int64 walks off the end of the embedding table (a GPU memory fault, not an exception), so every index / mask /
-    single-dtype argument is checked here and a mismatch is a TypeError."""
+    single-dtype argument is checked here and a mismatch is a TypeError.  The address carries its device index: call() launches
+    on that device and refuses arguments that live on different GPUs."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -126,11 +131,20 @@ def ptr(t: torch.Tensor | None, dtype: torch.dtype | None = None):
         raise Cm3pHipError("cm3p_amd kernels need contiguous tensors")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"cm3p_amd kernel argument has dtype {t.dtype}, the kernel reads {dtype}")
-    return t.data_ptr()
+    p = _DevPtr(t.data_ptr())
+    p.dev = t.device.index
+    return p
+
+
+class _StreamOfCall:
+    """Placeholder for "the current HIP stream of the device the tensor arguments live on"; call() resolves it."""
+
+
+_STREAM = _StreamOfCall()
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _STREAM
 
 
 def dt(t: torch.Tensor) -> int:
@@ -146,15 +160,16 @@ def dt(t: torch.Tensor) -> int:
 # caller attached.  Off (None) by default: zero overhead on the product path.
 _prof = None
 _prof_only = None
+HBM_BOUND_TAGS = set()  # tags whose `work` is algorithmic bytes rather than FLOPs (filled by kernels.py)
 
 
-def profile_begin(only: str | None = None):
+def profile_begin(only=None):
     """Start timing C-ABI calls with HIP events on the current stream.  `only`: time just the calls with this tag - an event pair
     around every launch costs the stream about 2.5 us each, ~5 ms of a C2 step, so the judged region of bench.py brackets only
     the dominant kernel's launches."""
     global _prof, _prof_only
     _prof = []
-    _prof_only = only
+    _prof_only = None if only is None else ({only} if isinstance(only, str) else set(only))
 
 
 def profile_end():
@@ -169,14 +184,37 @@ def profile_end():
     return out
 
 
+def _launch(name: str, args):
+    """Resolve the launch device from the pointer arguments (all must agree), run the C entry point under that device with its
+    current stream.  torch ops guard the device themselves; a drop-in user who did `model.to('cuda:1')` without
+    `torch.cuda.set_device(1)` must not get device-0 launches over device-1 pointers (a memory fault or silent peer access)."""
+    dev = None
+    for a in args:
+        if type(a) is _DevPtr:
+            if dev is None:
+                dev = a.dev
+            elif a.dev != dev:
+                raise Cm3pHipError(f"{name}: tensor arguments live on different GPUs (cuda:{dev} and cuda:{a.dev})")
+    if dev is None:
+        dev = torch.cuda.current_device()
+    fn = getattr(load(), name)
+    if dev == torch.cuda.current_device():
+        h = torch.cuda.current_stream(dev).cuda_stream
+        _check(fn(*[h if a is _STREAM else a for a in args]), name)
+    else:
+        with torch.cuda.device(dev):
+            h = torch.cuda.current_stream(dev).cuda_stream
+            _check(fn(*[h if a is _STREAM else a for a in args]), name)
+
+
 def call(name: str, *args, tag: str | None = None, work: float | None = None):
-    if _prof is None or (_prof_only is not None and (tag or name) != _prof_only):
-        _check(getattr(load(), name)(*args), name)
+    if _prof is None or (_prof_only is not None and (tag or name) not in _prof_only):
+        _launch(name, args)
         return
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    _check(getattr(load(), name)(*args), name)
+    _launch(name, args)
     e1.record()
     _prof.append((tag or name, e0, e1, work))
 

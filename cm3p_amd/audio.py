@@ -28,8 +28,11 @@ class _ConvGeluFn(torch.autograd.Function):
             B, C_in, T_in = xd.shape
         if C_in != Ci:
             raise ValueError(f"Conv1d expects {Ci} input channels, got {C_in}")  # (nn.Conv1d raises too; the kernel would read out of bounds)
-            if xd.dtype != torch.float32:
-                xd = xd.float()
+        # the channel-major kernel reads fp32, the token-major one bf16: bf16 / fp16 / fp64 mel features (the reference's
+        # extraction script passes bf16, ref:extract_beatmap_embeddings.py:228-230) are widened or narrowed first
+        want = torch.bfloat16 if token_major else torch.float32
+        if xd.dtype != want:
+            xd = xd.to(want)
         patches, T_out = K.im2col_k3(xd, token_major, B, Ci, T_in, stride)
         Wb = _bf16_weight(W.detach().reshape(Co, Ci * 3))
         b32 = _f32(bias.detach()).contiguous()
@@ -47,6 +50,8 @@ class _ConvGeluFn(torch.autograd.Function):
         dW = K.linear_wgrad(dz, patches).view(Co, Ci, 3)
         dx = None
         if ctx.needs_input_grad[0]:
+            if not token_major:  # (the mel features are data; the reference never differentiates through them either)
+                raise NotImplementedError("gradient w.r.t. channel-major conv input (input_features) is not implemented")
             dp = K.linear_dgrad(dz, Wb)
             dx = K.col2im_k3(dp, B, Ci, T_in, T_out, stride)
         return dx, dW.to(wd), db.to(bd), None, None, None

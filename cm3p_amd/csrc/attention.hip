@@ -723,15 +723,19 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t
     return CM3P_OK;
 }
 
+// stages: CM3P_ATTN_BWD_DQ (dq and delta) | CM3P_ATTN_BWD_DKV (dk, dv; reads the delta the dq stage wrote)
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                           const float* sin_tab, int64_t pos_batch_stride, VarLen vl, hipStream_t s) {
+                           const float* sin_tab, int64_t pos_batch_stride, VarLen vl, int stages, hipStream_t s) {
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
-                                                       key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
-    if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
-    attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                         key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+    if (stages & CM3P_ATTN_BWD_DQ) {
+        attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
+                                                           key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+    }
+    if (stages & CM3P_ATTN_BWD_DKV)
+        attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                             key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
     return CM3P_OK;
 }
 
@@ -749,13 +753,14 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
 
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                  const float* sin_tab, int64_t pos_batch_stride, void* stream) {
+                  const float* sin_tab, int64_t pos_batch_stride, int stages, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
+    CM3P_REQUIRE(stages >= 1 && stages <= 3);
     CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, window, scale, cos_tab, sin_tab,
-                                   pos_batch_stride, VarLen{nullptr, 0}, static_cast<hipStream_t>(stream));
+                                   pos_batch_stride, VarLen{nullptr, 0}, stages, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
@@ -774,12 +779,13 @@ int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_s
 
 int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                          const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
-                         const float* cos_tab, const float* sin_tab, void* stream) {
+                         const float* cos_tab, const float* sin_tab, int stages, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
+    CM3P_REQUIRE(stages >= 1 && stages <= 3);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, nullptr, B, max_seqlen, nh, window, scale, cos_tab, sin_tab, 0,
-                                   VarLen{cu_seqlens, total}, static_cast<hipStream_t>(stream));
+                                   VarLen{cu_seqlens, total}, stages, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;

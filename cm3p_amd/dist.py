@@ -2,16 +2,24 @@
 
 The reference never gathers: under DDP every rank contrasts only its own pairs.  With
 `model.gather_negatives = True` each rank all-gathers the L2-normalised (b, P) beatmap and metadata embeddings of every
-rank (one fused (b, 2, P) fp32 buffer; RCCL over xGMI on GPUs, gloo in the tests), scores its b rows against all
-N*b columns in both directions, and takes the cross-entropy with targets r*b + i.  Parity definition: with DDP's
-gradient averaging the parameter gradients equal those of the single-process loss on the concatenated N*b batch, and
-the mean of the per-rank losses equals that loss.
+rank (RCCL over xGMI on GPUs, gloo in the tests), scores its b rows against all N*b columns in both directions, and
+takes the cross-entropy with targets r*b + i.  Parity definition: with DDP's gradient averaging the parameter gradients
+equal those of the single-process loss on the concatenated N*b batch, and the mean of the per-rank losses equals that
+loss.
 
-The autograd node below is torch.distributed plumbing and device agnostic; the arithmetic around it (logits, loss) is
-the HIP head of modeling_cm3p.py.  Its backward is the transpose collective: a sum reduce-scatter of the gradient
-w.r.t. the gathered buffer, so gradients that other ranks hold for this rank's embeddings come home.
+Overlap: a gather is STARTED as soon as its embeddings exist (`start_gather`, an asynchronous collective: on RCCL it runs
+on the process group's own HIP stream, ordered after the producer kernels by an event, while the compute stream goes on)
+and JOINED only where the logits need it (`PendingGather.wait`).  CM3PModel.forward starts the beatmap gather right after
+the beatmap projection, so it travels under the whole metadata tower; the metadata gather, whose result is needed at once,
+is the only exposed one (64 KiB per rank at b = 32).
+
+The autograd node is torch.distributed plumbing and device agnostic; the arithmetic around it (logits, loss) is the HIP
+head of modeling_cm3p.py.  Its backward is the transpose collective: a sum reduce-scatter of the gradient w.r.t. the
+gathered buffer, so gradients that other ranks hold for this rank's embeddings come home.
 """
 from __future__ import annotations
+
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -20,15 +28,22 @@ Tensor = torch.Tensor
 
 
 class AllGatherEmbeds(torch.autograd.Function):
-    """(b, ...) -> (N*b, ...) concatenated in rank order; backward = reduce-scatter(sum)."""
+    """(b, ...) -> (N*b, ...) concatenated in rank order; backward = reduce-scatter(sum).
+
+    With `holder` (a list) the forward only STARTS the collective and appends its work handle: the returned tensor must not be
+    read before `holder[0].wait()` (PendingGather does that)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, group=None):
+    def forward(ctx, x: Tensor, group=None, holder=None):
         ctx.group = group
         world = dist.get_world_size(group)
         x = x.contiguous()
         out = torch.empty((world * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=group)
+        if holder is None:
+            dist.all_gather_into_tensor(out, x, group=group)
+        else:
+            holder.append(dist.all_gather_into_tensor(out, x, group=group, async_op=True))
+            holder.append(x)  # the send buffer stays alive until the join
         return out
 
     @staticmethod
@@ -44,31 +59,62 @@ class AllGatherEmbeds(torch.autograd.Function):
             out.copy_(g[r * out.shape[0]:(r + 1) * out.shape[0]])
         else:
             dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return out, None
+        return out, None, None
+
+
+class PendingGather:
+    """An all-gather in flight: `.wait()` joins it into the calling stream and returns the (N*b, ...) tensor."""
+
+    def __init__(self, x: Tensor, group=None):
+        self._holder: list = []
+        self._out = AllGatherEmbeds.apply(x, group, self._holder)
+
+    def wait(self) -> Tensor:
+        if self._holder:
+            self._holder[0].wait()  # RCCL: the current stream waits for the collective's stream; gloo: blocks the host
+            self._holder.clear()
+        return self._out
+
+
+def start_gather(x: Tensor, group=None) -> PendingGather:
+    return PendingGather(x, group)
 
 
 def gather_pair(metadata_embeds: Tensor, beatmap_embeds: Tensor, group=None):
-    """One collective for both modalities: (b, P), (b, P) -> (N*b, P), (N*b, P).
-
-    The fused buffer is 2*b*P fp32 (128 KiB at b = 32): latency-bound, a few tens of microseconds on RCCL, and the
-    logits need it immediately, so it is issued on the compute stream (a side stream would buy nothing here and would
-    need cross-stream allocator bookkeeping)."""
-    fused = torch.stack((metadata_embeds, beatmap_embeds), dim=1)  # (b, 2, P): layout only, no arithmetic
-    allf = AllGatherEmbeds.apply(fused, group)
-    return allf[:, 0].contiguous(), allf[:, 1].contiguous()
+    """Both modalities: (b, P), (b, P) -> (N*b, P), (N*b, P), two collectives started back to back and joined together."""
+    pm, pb = start_gather(metadata_embeds, group), start_gather(beatmap_embeds, group)
+    return pm.wait(), pb.wait()
 
 
-def gathered_contrastive(metadata_embeds: Tensor, beatmap_embeds: Tensor, logit_scale: Tensor, group=None):
-    """-> (logits_per_metadata (b, N*b), logits_per_beatmap (b, N*b), loss) on this rank (HIP head)."""
+def gathered_contrastive(metadata_embeds: Tensor, beatmap_embeds: Tensor, logit_scale: Tensor, group=None,
+                         beatmap_pending: PendingGather | None = None):
+    """-> (logits_per_metadata (b, N*b), logits_per_beatmap (b, N*b), loss) on this rank (HIP head).  `beatmap_pending`: the
+    beatmap gather the caller started earlier (it has been travelling under the metadata tower)."""
     from .modeling_cm3p import _CrossEntropySumFn, _LogitsFn
 
     r = dist.get_rank(group)
     b = metadata_embeds.shape[0]
-    m_all, b_all = gather_pair(metadata_embeds, beatmap_embeds, group)
+    pm = start_gather(metadata_embeds, group)
+    pb = beatmap_pending if beatmap_pending is not None else start_gather(beatmap_embeds, group)
+    b_all = pb.wait()
     lpm = _LogitsFn.apply(metadata_embeds, b_all, logit_scale)  # this rank's metadata rows vs every beatmap
+    m_all = pm.wait()
     lpb = _LogitsFn.apply(beatmap_embeds, m_all, logit_scale)   # this rank's beatmap rows vs every metadata
     n = lpm.shape[1]
     target = torch.arange(r * b, (r + 1) * b, device=lpm.device, dtype=torch.int64)
     specs = [(0, b, n, n, 1, None, target, 0.5), (1, b, n, n, 1, None, target, 0.5)]
     loss = _CrossEntropySumFn.apply(specs, lpm, lpb)
     return lpm, lpb, loss
+
+
+_warned_3d = False
+
+
+def warn_variations_stay_local():
+    """gather_negatives with (B, V, L) metadata variations: the variations are per-sample structured negatives and stay
+    rank-local (decided and documented in DESIGN.md §6); say so once instead of silently ignoring the flag."""
+    global _warned_3d
+    if not _warned_3d:
+        _warned_3d = True
+        warnings.warn("CM3PModel.gather_negatives is set but metadata_ids is (B, V, L): metadata variations are rank-local "
+                      "negatives; this batch is scored without cross-rank gathering.", RuntimeWarning, stacklevel=3)

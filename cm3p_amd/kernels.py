@@ -13,6 +13,9 @@ from ._lib import BF16, EPI_BF16, EPI_F32, EPI_F32_RESID, F32, call, dt, ptr, qu
 
 Tensor = torch.Tensor
 
+# C-ABI calls whose `work` is algorithmic BYTES (HBM-bound row-wise kernels); every other `work` is matmul FLOPs
+_lib.HBM_BOUND_TAGS.update({"cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd"})
+
 
 def _empty(shape, dtype, like: Tensor) -> Tensor:
     return torch.empty(shape, dtype=dtype, device=like.device)
@@ -26,7 +29,8 @@ def layernorm_fwd(x: Tensor, weight: Tensor, eps: float, want_f32: bool, want_bf
     y16 = _empty((rows, H), torch.bfloat16, x) if want_bf16 else None
     mean = _empty((rows,), torch.float32, x) if want_stats else None
     rstd = _empty((rows,), torch.float32, x) if want_stats else None
-    call("cm3p_layernorm_fwd", ptr(x), dt(x), ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), rows, H, eps, stream())
+    call("cm3p_layernorm_fwd", ptr(x), dt(x), ptr(weight, torch.float32), ptr(y32), ptr(y16), ptr(mean, torch.float32), ptr(rstd, torch.float32), rows, H, eps, stream(),
+         work=float(rows) * H * (x.element_size() + (4 if want_f32 else 0) + (2 if want_bf16 else 0)))
     return y32, y16, mean, rstd
 
 
@@ -40,7 +44,8 @@ def layernorm_bwd(dy: Tensor, x: Tensor, weight: Tensor, mean: Tensor, rstd: Ten
     part = _empty((nblk, H), torch.float32, x)
     dw = _empty((H,), torch.float32, x)
     call("cm3p_layernorm_bwd", ptr(dy), dt(dy), ptr(x), ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(dres), ptr(dx32), ptr(dx16),
-         ptr(part), ptr(dw), rows, H, stream())
+         ptr(part), ptr(dw), rows, H, stream(),
+         work=float(rows) * H * (dy.element_size() + 4 + (4 if dres is not None else 0) + 4 + (2 if want_bf16 else 0)))
     return dx32, dx16, dw
 
 
@@ -62,7 +67,9 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
     T = ids.numel()
     V, H = table.shape
     d_table = torch.zeros((V, H), dtype=torch.float32, device=table.device) if want_table_grad else None
-    d_ovr = _empty(override.shape, torch.float32, table) if override is not None else None
+    # zeros, not empty: in unpadded execution placeholder tokens at masked positions are dropped from the packed rows, their
+    # rows are never written by the kernel, and zero is their true gradient
+    d_ovr = torch.zeros(override.shape, dtype=torch.float32, device=table.device) if override is not None else None
     nblk = query("cm3p_layernorm_bwd_blocks", T)
     part = _empty((nblk, H), torch.float32, table)
     dw = _empty((H,), torch.float32, table)
@@ -174,15 +181,24 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
     return out, lse
 
 
+ATTN_BWD_DQ, ATTN_BWD_DKV = 1, 2  # stages of cm3p_attn_bwd (include/cm3p_hip.h)
+
+
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
              window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False) -> Tensor:
-    """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM)."""
+    """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM).
+    The two kernels are issued as two C calls so that each has its own profiler tag (one rocprof row per tag).  `work` is the
+    algorithmic count of SURVEY.md section 8(d) (backward = 2 x forward = four matmuls: dQ is the dq kernel's, dP / dV / dK the
+    dkv kernel's); the scores each kernel recomputes are not credited."""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
-    call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh, window, scale,
-         ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stream(), tag="attn_bwd(dq+dkv)" + ("<global>" if window < 0 else "<local>"), work=8.0 * B * nh * S * keys * 64)
+    kind = "<global>" if window < 0 else "<local>"
+    for stage, name, products in ((ATTN_BWD_DQ, "attn_bwd_dq_kernel", 1), (ATTN_BWD_DKV, "attn_bwd_dkv_kernel", 3)):
+        call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh,
+             window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, stream(), tag=name + kind,
+             work=2.0 * products * B * nh * S * keys * 64)
     return dqkv
 
 
@@ -202,8 +218,10 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
-    call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s, qkv.shape[0], nh,
-         window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stream(), tag="attn_bwd(dq+dkv)" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+    kind = "<global,varlen>" if window < 0 else "<local,varlen>"
+    for stage, name in ((ATTN_BWD_DQ, "attn_bwd_dq_kernel"), (ATTN_BWD_DKV, "attn_bwd_dkv_kernel")):
+        call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s,
+             qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, stream(), tag=name + kind)
     return dqkv
 
 
@@ -225,13 +243,13 @@ def scatter_rows(src: Tensor, idx: Tensor, rows: int) -> Tensor:
 def geglu_fwd(h: Tensor) -> Tensor:
     T, I2 = h.shape
     g = torch.empty((T, I2 // 2), dtype=torch.bfloat16, device=h.device)
-    call("cm3p_geglu_fwd", ptr(h), ptr(g), T, I2 // 2, stream())
+    call("cm3p_geglu_fwd", ptr(h), ptr(g), T, I2 // 2, stream(), work=6.0 * T * (I2 // 2))
     return g
 
 
 def geglu_bwd(dg: Tensor, h: Tensor) -> Tensor:
     dh = torch.empty_like(h)
-    call("cm3p_geglu_bwd", ptr(dg), ptr(h), ptr(dh), h.shape[0], h.shape[1] // 2, stream())
+    call("cm3p_geglu_bwd", ptr(dg), ptr(h), ptr(dh), h.shape[0], h.shape[1] // 2, stream(), work=10.0 * h.shape[0] * (h.shape[1] // 2))
     return dh
 
 
@@ -251,7 +269,7 @@ def gelu_bwd(dy: Tensor, x: Tensor) -> Tensor:
 def im2col_k3(x: Tensor, token_major: bool, B: int, C: int, T_in: int, stride: int):
     T_out = (T_in - 1) // stride + 1
     p = torch.empty((B * T_out, C * 3), dtype=torch.bfloat16, device=x.device)
-    call("cm3p_im2col_k3", ptr(x), int(token_major), ptr(p), B, C, T_in, T_out, stride, stream())
+    call("cm3p_im2col_k3", ptr(x, torch.bfloat16 if token_major else torch.float32), int(token_major), ptr(p), B, C, T_in, T_out, stride, stream())
     return p, T_out
 
 

@@ -627,7 +627,7 @@ class CM3PModel(CM3PPreTrainedModel):
         if output_logits and not self.config.has_decoder_head:
             raise ValueError("Cannot return logits when the model is not configured with a decoder head.")
 
-        beatmap_embeds = beatmap_outputs = metadata_embeds = metadata_outputs = None
+        beatmap_embeds = beatmap_outputs = metadata_embeds = metadata_outputs = beatmap_pending = None
         logits_per_beatmap = logits_per_metadata = None
         loss = 0 if return_loss else None
 
@@ -639,6 +639,17 @@ class CM3PModel(CM3PPreTrainedModel):
                                                  cu_seqlens=cu_seqlens, output_attentions=output_attentions,
                                                  output_hidden_states=output_hidden_states)
             beatmap_embeds = _L2NormFn.apply(_ProjectFn.apply(beatmap_outputs.pooler_output, self.beatmap_projection.weight))
+            if self.gather_negatives and metadata_ids is not None:
+                if metadata_ids.dim() == 2:
+                    # start the all-gather now: it runs on the process group's side stream under the whole metadata tower and is
+                    # joined just before the logits (cm3p_amd/dist.py)
+                    from .dist import start_gather
+
+                    beatmap_pending = start_gather(beatmap_embeds)
+                else:
+                    from .dist import warn_variations_stay_local
+
+                    warn_variations_stay_local()
 
         if metadata_ids is not None:
             metadata_outputs = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
@@ -652,7 +663,8 @@ class CM3PModel(CM3PPreTrainedModel):
             if self.gather_negatives and metadata_embeds.dim() == 2:
                 from .dist import gathered_contrastive
 
-                logits_per_metadata, logits_per_beatmap, gl = gathered_contrastive(me2, beatmap_embeds, self.logit_scale)
+                logits_per_metadata, logits_per_beatmap, gl = gathered_contrastive(me2, beatmap_embeds, self.logit_scale,
+                                                                                   beatmap_pending=beatmap_pending)
                 if return_loss:
                     loss = gl
             else:

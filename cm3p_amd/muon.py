@@ -171,56 +171,61 @@ class Muon(torch.optim.Optimizer):
                 continue
             device = (adamw[0][0] if adamw else next(iter(shape_groups.values()))[0][0]).device
 
-            # every address table of this step in one host buffer -> one H2D copy
-            table: list[int] = []
-            layout = {}
-            for key, items in shape_groups.items():
-                for j, name in enumerate(("p", "g", "buf")):
-                    layout[(key, name)] = len(table)
-                    table.extend(it[j].data_ptr() for it in items)
-            # the AdamW rule's bias-correction scale depends on the per-parameter step count: one launch per distinct count
-            adamw_by_step: dict = {}
-            for p, g, state in adamw:
-                adamw_by_step.setdefault(state["step"], []).append((p, g, state))
-            for t, items in adamw_by_step.items():
-                for name, col in (("p", [p.data_ptr() for p, _, _ in items]), ("g", [g.data_ptr() for _, g, _ in items]),
-                                  ("m1", [s["moment1"].data_ptr() for _, _, s in items]),
-                                  ("m2", [s["moment2"].data_ptr() for _, _, s in items]), ("n", [p.numel() for p, _, _ in items])):
-                    layout[("adamw", t, name)] = len(table)
-                    table.extend(col)
-            dev_table = torch.tensor(table, dtype=torch.int64).to(device, non_blocking=True)
-            base = dev_table.data_ptr()
-            st = stream()
-
-            for key, items in shape_groups.items():
-                rows, cols = key
-                n = len(items)
-                ws = self._workspace((gi, key), n, rows, cols, device)
-                aligned = all(it[1].data_ptr() % 16 == 0 and it[2].data_ptr() % 16 == 0 for it in items)
-                numel = rows * cols
-                call("cm3p_muon_momentum", base + 8 * layout[(key, "g")], base + 8 * layout[(key, "buf")], ws.X.data_ptr(),
-                     ws.partials.data_ptr(), n, rows, cols, ws.cp, ws.x_stride, float(momentum), int(bool(group["nesterov"])),
-                     int(aligned), st, tag="muon_momentum", work=14.0 * n * numel)
-                call("cm3p_muon_normalize", ws.X.data_ptr(), ws.partials.data_ptr(), n, rows, cols, ws.x_stride, NS_EPS, st,
-                     tag="muon_normalize", work=4.0 * n * ws.x_stride)
-                out = newton_schulz_batched(ws, int(group["ns_steps"]))
-                call("cm3p_muon_apply", base + 8 * layout[(key, "p")], out.data_ptr(), n, rows, cols, ws.cp, ws.x_stride,
-                     float(max(1, rows / cols) ** 0.5), float(-lr), st, tag="muon_apply", work=10.0 * n * numel)
-                if out is ws.X2:  # keep "X holds the next step's input, X2 is scratch" (odd iteration counts swap them)
-                    ws.X, ws.X2 = ws.X2, ws.X
-
-            b1, b2 = group["adamw_betas"]
-            adamw_lr = lr * group["adamw_lr_ratio"]
-            for t, items in adamw_by_step.items():
-                scale = (1 - b1 ** t) / (1 - b2 ** t) ** 0.5
-                call("cm3p_adamw_multi", base + 8 * layout[("adamw", t, "p")], base + 8 * layout[("adamw", t, "g")],
-                     base + 8 * layout[("adamw", t, "m1")], base + 8 * layout[("adamw", t, "m2")], base + 8 * layout[("adamw", t, "n")],
-                     len(items), max(p.numel() for p, _, _ in items), float(1 - b1), float(1 - b2), float(group["adamw_eps"]),
-                     float(1 - adamw_lr * group["adamw_wd"]), float(-lr / scale), st, tag="adamw_multi",
-                     work=28.0 * sum(p.numel() for p, _, _ in items))
-            # dev_table must outlive the launches above: they are stream-ordered before any later reuse of its memory by
-            # torch's caching allocator on this same stream.
+            # launches below take raw addresses (no tensor to read the device from): make the parameters' GPU current
+            with torch.cuda.device(device):
+                self._step_group(gi, group, shape_groups, adamw, device, lr, momentum)
         return loss
+
+    def _step_group(self, gi, group, shape_groups, adamw, device, lr, momentum):
+        # every address table of this step in one host buffer -> one H2D copy
+        table: list[int] = []
+        layout = {}
+        for key, items in shape_groups.items():
+            for j, name in enumerate(("p", "g", "buf")):
+                layout[(key, name)] = len(table)
+                table.extend(it[j].data_ptr() for it in items)
+        # the AdamW rule's bias-correction scale depends on the per-parameter step count: one launch per distinct count
+        adamw_by_step: dict = {}
+        for p, g, state in adamw:
+            adamw_by_step.setdefault(state["step"], []).append((p, g, state))
+        for t, items in adamw_by_step.items():
+            for name, col in (("p", [p.data_ptr() for p, _, _ in items]), ("g", [g.data_ptr() for _, g, _ in items]),
+                              ("m1", [s["moment1"].data_ptr() for _, _, s in items]),
+                              ("m2", [s["moment2"].data_ptr() for _, _, s in items]), ("n", [p.numel() for p, _, _ in items])):
+                layout[("adamw", t, name)] = len(table)
+                table.extend(col)
+        dev_table = torch.tensor(table, dtype=torch.int64).to(device, non_blocking=True)
+        base = dev_table.data_ptr()
+        st = stream()
+
+        for key, items in shape_groups.items():
+            rows, cols = key
+            n = len(items)
+            ws = self._workspace((gi, key), n, rows, cols, device)
+            aligned = all(it[1].data_ptr() % 16 == 0 and it[2].data_ptr() % 16 == 0 for it in items)
+            numel = rows * cols
+            call("cm3p_muon_momentum", base + 8 * layout[(key, "g")], base + 8 * layout[(key, "buf")], ws.X.data_ptr(),
+                 ws.partials.data_ptr(), n, rows, cols, ws.cp, ws.x_stride, float(momentum), int(bool(group["nesterov"])),
+                 int(aligned), st, tag="muon_momentum", work=14.0 * n * numel)
+            call("cm3p_muon_normalize", ws.X.data_ptr(), ws.partials.data_ptr(), n, rows, cols, ws.x_stride, NS_EPS, st,
+                 tag="muon_normalize", work=4.0 * n * ws.x_stride)
+            out = newton_schulz_batched(ws, int(group["ns_steps"]))
+            call("cm3p_muon_apply", base + 8 * layout[(key, "p")], out.data_ptr(), n, rows, cols, ws.cp, ws.x_stride,
+                 float(max(1, rows / cols) ** 0.5), float(-lr), st, tag="muon_apply", work=10.0 * n * numel)
+            if out is ws.X2:  # keep "X holds the next step's input, X2 is scratch" (odd iteration counts swap them)
+                ws.X, ws.X2 = ws.X2, ws.X
+
+        b1, b2 = group["adamw_betas"]
+        adamw_lr = lr * group["adamw_lr_ratio"]
+        for t, items in adamw_by_step.items():
+            scale = (1 - b1 ** t) / (1 - b2 ** t) ** 0.5
+            call("cm3p_adamw_multi", base + 8 * layout[("adamw", t, "p")], base + 8 * layout[("adamw", t, "g")],
+                 base + 8 * layout[("adamw", t, "m1")], base + 8 * layout[("adamw", t, "m2")], base + 8 * layout[("adamw", t, "n")],
+                 len(items), max(p.numel() for p, _, _ in items), float(1 - b1), float(1 - b2), float(group["adamw_eps"]),
+                 float(1 - adamw_lr * group["adamw_wd"]), float(-lr / scale), st, tag="adamw_multi",
+                 work=28.0 * sum(p.numel() for p, _, _ in items))
+        # dev_table must outlive the launches above: they are stream-ordered before any later reuse of its memory by
+        # torch's caching allocator on this same stream.
 
 
 __all__ = ["Muon", "newton_schulz_batched"]

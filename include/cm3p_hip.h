@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 7
+#define CM3P_ABI_VERSION 8
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -143,10 +143,15 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
                   float scale, void* stream);
 /* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten.
  * If cos_tab/sin_tab are not NULL the inverse rotary rotation is applied to dq and dk before they are stored (the
- * backward of apply_rotary_pos_emb), with pos_batch_stride = 0 (one position row for all batches) or S. */
+ * backward of apply_rotary_pos_emb), with pos_batch_stride = 0 (one position row for all batches) or S.
+ * stages: which of the backward's kernels to launch - CM3P_ATTN_BWD_DQ (the dq third of dqkv, and delta),
+ * CM3P_ATTN_BWD_DKV (the dk and dv thirds; reads the delta a DQ stage wrote earlier on the same stream), or both (3).
+ * Callers that time kernels one by one issue the stages as two calls; the results are identical. */
+#define CM3P_ATTN_BWD_DQ 1
+#define CM3P_ATTN_BWD_DKV 2
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                  const float* sin_tab, int64_t pos_batch_stride, void* stream);
+                  const float* sin_tab, int64_t pos_batch_stride, int stages, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GeGLU: g = gelu_erf(h[:, :I]) * h[:, I:]   (ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91).
@@ -261,7 +266,7 @@ int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_s
                          int nh, int window, float scale, void* stream);
 int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                          const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
-                         const float* cos_tab, const float* sin_tab, void* stream);
+                         const float* cos_tab, const float* sin_tab, int stages, void* stream);
 int cm3p_gather_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
 int cm3p_scatter_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
 

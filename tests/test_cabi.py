@@ -67,3 +67,16 @@ def test_cpu_tensors_are_refused(lib_path):
     x = torch.zeros(4, 64)
     with pytest.raises(_lib.Cm3pHipError):
         kernels.layernorm_fwd(x, torch.ones(64), 1e-5, True, False)
+
+
+def test_pointer_arguments_on_different_gpus_are_refused():
+    """call() launches on the device its tensor arguments live on and refuses a mix (a device-0 launch over device-1 pointers
+    is a memory fault or a silent peer access); checked before anything touches a GPU, so it runs here."""
+    import pytest
+
+    from cm3p_amd import _lib
+
+    a, b = _lib._DevPtr(4096), _lib._DevPtr(8192)
+    a.dev, b.dev = 0, 1
+    with pytest.raises(_lib.Cm3pHipError, match="different GPUs"):
+        _lib._launch("cm3p_cast_f32_bf16", (a, b, 16, _lib.stream()))

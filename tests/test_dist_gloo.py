@@ -41,13 +41,18 @@ def _worker(rank, world, port, b, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from cm3p_amd.dist import gather_pair
+        from cm3p_amd.dist import start_gather
 
         params, xm, xb = _make(world, b)
         params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         sl = slice(rank * b, (rank + 1) * b)
-        me, be = _towers(params, xm[sl], xb[sl])
-        m_all, b_all = gather_pair(me, be)
+        # the product's order of events (CM3PModel.forward): the beatmap gather is started as soon as its embeddings exist,
+        # the metadata tower runs while it is in flight, both gathers are joined only where the logits need them
+        be = _towers(params, xm[sl], xb[sl])[1]
+        pending_b = start_gather(be)
+        me = _towers(params, xm[sl], xb[sl])[0]
+        pending_m = start_gather(me)
+        b_all, m_all = pending_b.wait(), pending_m.wait()
         assert m_all.shape == (world * b, 16)
         scale = params["s"].exp()
         target = torch.arange(rank * b, (rank + 1) * b)
@@ -65,7 +70,7 @@ def _worker(rank, world, port, b, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b", [(2, 3), (2, 1)])
+@pytest.mark.parametrize("world,b", [(2, 3), (2, 1), (4, 2)])  # 2 and 4 processes
 def test_gathered_loss_and_grads_equal_single_process_reference(world, b):
     from oracle import cm3p_oracle as O
 

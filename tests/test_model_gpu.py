@@ -309,6 +309,53 @@ def test_unpadded_and_padded_paths_agree_and_full_batches_stay_padded():
     assert abs(oc.loss.item() - full["loss"].item()) <= 3e-2
 
 
+def test_unpadded_audio_placeholders_inside_the_padding_get_zero_gradient():
+    """A right-padded row whose valid length ends inside the audio placeholder run: in unpadded execution those placeholder
+    tokens are dropped from the packed rows, so the embedding backward never writes their audio rows - they must come back as
+    exact zeros (their true gradient), not as uninitialised memory flowing into the projector / audio-encoder gradients."""
+    name = "d64_audio"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    inp = _inputs(blob)
+    n_audio = int((inp["input_ids"][1] == CASES[name]["cfg"]["beatmap_config"]["audio_token_id"]).sum())
+    cut = 1 + n_audio // 2  # row 1 keeps [AUDIO_BOS] + half of its placeholders; the rest sits in the padding
+    inp["attention_mask"] = inp["attention_mask"].clone()
+    inp["attention_mask"][1, cut:] = 0
+    grads = {}
+    for unpad in (False, True):
+        model = _build(name)
+        model.unpad_inputs = unpad
+        # poison the allocator's free blocks so that "uninitialised" is visibly wrong
+        junk = torch.full((64, 1024, 256), float("nan"), device=DEV)
+        del junk
+        out = model(**inp)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        grads[unpad] = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()
+                        if p.grad is not None and k.startswith("beatmap_model.audio_encoder.")}
+        assert grads[unpad] and all(torch.isfinite(g).all() for g in grads[unpad].values())
+    for k, g in grads[True].items():
+        ref = grads[False][k]
+        if ref.norm() > 1e-8:
+            assert _rel(g, ref) <= 2e-2, f"{k}: {_rel(g, ref):.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float64])
+def test_audio_features_of_any_float_dtype(dtype):
+    """The reference's extraction script passes bf16 mel features (ref:extract_beatmap_embeddings.py:228-230); the channel-major
+    im2col kernel reads fp32, so other dtypes are converted first (reading bf16 as fp32 would walk off the buffer)."""
+    name = "d64_audio"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name).eval()
+    inp = _inputs(blob)
+    with torch.no_grad():
+        want = model(**inp)
+        inp["input_features"] = inp["input_features"].to(dtype)
+        got = model(**inp)
+    tol = 1e-6 if dtype == torch.float64 else 3e-2  # bf16 / fp16 features are themselves rounded inputs
+    assert _rel(got.beatmap_embeds, want.beatmap_embeds) <= tol
+    assert _rel(got.beatmap_model_output.audio_model_output.audio_embeds, want.beatmap_model_output.audio_model_output.audio_embeds) <= tol
+
+
 # ------------------------------------------------------------------------------------------------- inference consumers
 def test_extraction_and_variation_eval_paths():
     """the two forward-only consumers of the same kernels.
