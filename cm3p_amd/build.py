@@ -10,9 +10,12 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "attention.hip", "head.hip", "conv.hip", "muon.hip"]
+SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "attention.hip", "attention_bwd.hip", "head.hip", "conv.hip", "muon.hip"]
 LIB = os.path.join(CSRC, "libcm3p_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# hand-scheduled kernels: SLP-packing adjacent f32 multiplies into v_pk_mul_f32 costs register shuffles (v_mov / v_perm /
+# v_alignbit) around the bf16 packs and packed f32 VALU is slower beside MFMAs (MI355X_MICROARCH.md, cycle constants)
+EXTRA_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -24,7 +27,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "..", "..", "include", "cm3p_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "..", "..", "include", "cm3p_hip.h")]
     objs = []
     procs = []
     for src in SOURCES:
@@ -32,7 +35,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -18,130 +18,11 @@
 //            dV^T += dO^T P and dK^T += Q^T dS consume the accumulators directly as B operands.
 // LDS tiles use one swizzled image (128-byte rows) that is bank-conflict free for ds_read_b128 row fragments AND for
 // ds_read_b64_tr_b16 transposed reads, so a tile consumed both ways (K in dq; Q and dO in dk/dv) is stored once.
-#include <limits.h>
+#include <stdlib.h>
 
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
-
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kNegInf = -__builtin_huge_valf();
-
-// ONE LDS image serves both access shapes (128-byte rows of 64 bf16, 16-byte chunk index XOR swz(row)):
-//   row fragments   (ds_read_b128, lane = row, fixed chunk): the 8 even / 8 odd rows of every 16-lane group get 8 different
-//                   swz values -> 16 different 16-byte slots of the 256-byte bank row;
-//   transposed reads (ds_read_b64_tr_b16, 4 rows x 64 bytes per 32-lane half): rows b, b+1 sit in different halves of the
-//                   bank row and bit 2 of swz moves rows b+2, b+3 to the other aligned group of four chunks.
-__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int off_R(int row, int c16) { return row * 128 + ((c16 ^ swz(row)) << 4); }
-__device__ __forceinline__ int off_T(int row, int col) { return row * 128 + (((col >> 3) ^ swz(row)) << 4) + ((col & 7) << 1); }
-
-// hardware workgroup id -> logical id such that each XCD (workgroup n runs on XCD n % 8) owns a contiguous range of logical
-// ids (bijective for any grid size)
-__device__ __forceinline__ int xcd_remap(int n, int total) {
-    const int q8 = total / 8, r8 = total % 8, xcd = n % 8;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + n / 8;
-}
-// 1-D grid of nblk * nh * B workgroups -> (block along the sequence, head, batch), XCD-aware: the blocks of one
-// (batch, head) are consecutive logical ids, so they run on ONE XCD and share its L2 copy of that head's K / V (or Q / dO)
-// instead of pulling it into all eight L2s.  Speed only (measured: forward 2.20 -> 2.10 ms, backward 6.60 -> 6.42 ms per C2
-// global layer); any order is correct.
-__device__ __forceinline__ void decode_block(int nblk, int nh, int& blk, int& head, int& b) {
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    blk = logical % nblk;
-    const int bh = logical / nblk;
-    head = bh % nh;
-    b = bh / nh;
-}
-
-// Unpadded ("varlen") batches: sequences are packed back to back, sequence b occupies rows cu[b] .. cu[b+1]-1 of the
-// [total, ...] tensors (the layout the reference's flash_attention_2 path builds with _unpad_cm3p_input,
-// ref:cm3p/modeling_cm3p.py:65-134) and the per-row statistics are [nh, total].  cu == nullptr: padded [B, S, ...] tensors.
-struct VarLen {
-    const int* cu;
-    int64_t total;
-};
-struct SeqView {
-    int64_t row0;   // first row of this sequence in the token-major tensors
-    int64_t stat0;  // index of its row 0 in lse / delta for this head
-    int S;          // its length
-    bool packed;
-    __device__ __forceinline__ SeqView(const VarLen& vl, int b, int head, int Smax, int nh) {
-        packed = vl.cu != nullptr;
-        if (packed) {
-            row0 = vl.cu[b];
-            S = vl.cu[b + 1] - vl.cu[b];
-            stat0 = (int64_t)head * vl.total + row0;
-        } else {
-            row0 = (int64_t)b * Smax;
-            S = Smax;
-            stat0 = ((int64_t)b * nh + head) * Smax;
-        }
-    }
-    // first row of the rotary tables for this sequence: packed tables are per token; padded ones per batch row or shared
-    __device__ __forceinline__ int64_t pos0(int b, int64_t pos_batch_stride) const { return packed ? row0 : (int64_t)b * pos_batch_stride; }
-};
-
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// A-operand fragment of X^T (rows = the 64 columns of tile X, k = 16 rows of X starting at krow0) for the product
-// X^T * Y where Y comes from accumulators: element j of lane half hh is row krow0 + 8*(j>>2) + 4*hh + (j&3) of X.
-// `cblk` selects columns 32*cblk .. 32*cblk+31 of X (the MFMA's 32 output rows).
-__device__ __forceinline__ bf16x8 frag_T(const char* tile, int krow0, int cblk, int lane) {
-    const int g = lane >> 4, hh = g >> 1, i = lane & 15;
-    const int row = krow0 + 4 * hh + (i >> 2);
-    const int col = 32 * cblk + 16 * (g & 1) + 4 * (i & 3);
-    const bf16x4 lo = lds_read_tr16(tile + off_T(row, col));
-    const bf16x4 hi = lds_read_tr16(tile + off_T(row + 8, col));
-    return cat_bf16x4(lo, hi);
-}
-
-// Row fragment (A or B operand): lane holds X[row0 + (lane&31)][16*s + 8*(lane>>5) + j]
-__device__ __forceinline__ bf16x8 frag_R(const char* tile, int row0, int s, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + off_R(row0 + (lane & 31), 2 * s + (lane >> 5)));
-}
-
-// accumulator registers 8*sp .. 8*sp+7 -> bf16 B-operand fragment for k-step sp
-__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sp) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * sp + j];
-    return r;
-}
-
-// fragment * c, rounded back to bf16: folds softmax's scale*log2(e) into one MFMA operand so that the accumulator is
-// already in exp2 units (saves one VALU op per score)
-__device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float c) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((float)v[j] * c);
-    return r;
-}
-
-__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-
-struct TileRegs64 {  // a 64-row x 64-col bf16 tile spread over 256 threads: 2 x 16 bytes each
-    uint4 v[2];
-};
-
-// rows r0 .. r0+63 of a [*, 64] bf16 matrix with row stride `ld` elements; rows >= limit read as zero
-__device__ __forceinline__ void gload64(TileRegs64& t, const uint16_t* base, int64_t ld, int r0, int limit, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-        const int r = r0 + row;
-        t.v[i] = (r < limit && r >= 0) ? *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + c * 8) : uint4{0u, 0u, 0u, 0u};
-    }
-}
-__device__ __forceinline__ void lstore64_R(char* tile, const TileRegs64& t, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-        *reinterpret_cast<uint4*>(tile + off_R(row, c)) = t.v[i];
-    }
-}
 
 __device__ __forceinline__ float reg_max16(const f32x16& a) {  // 8 x v_max3_f32
     const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
@@ -723,10 +604,24 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t
     return CM3P_OK;
 }
 
+// attention_bwd.hip: the global-layer (window < 0) backward kernels
+int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                const uint8_t* key_mask, int B, int S, int nh, float scale, const float* cos_tab, const float* sin_tab,
+                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, hipStream_t s);
+
+// Kernel experiments only: CM3P_ATTN_BWD_BAND_EVERYWHERE=1 routes global layers through the band kernels below as well.
+static bool band_kernels_everywhere() {
+    static const bool v = [] { const char* e = getenv("CM3P_ATTN_BWD_BAND_EVERYWHERE"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // stages: CM3P_ATTN_BWD_DQ (dq and delta) | CM3P_ATTN_BWD_DKV (dk, dv; reads the delta the dq stage wrote)
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
                            const float* sin_tab, int64_t pos_batch_stride, VarLen vl, int stages, hipStream_t s) {
+    if (window < 0 && !band_kernels_everywhere())
+        return cm3p_launch_attn_bwd_global(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, scale, cos_tab, sin_tab, pos_batch_stride,
+                                           vl.cu, vl.total, stages, s);
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     if (stages & CM3P_ATTN_BWD_DQ) {
         attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,

@@ -1,0 +1,748 @@
+// Backward of the GLOBAL attention layers (window < 0), head_dim 64, gfx950: the kernels of cm3p_attn_bwd / cm3p_attn_bwd_varlen
+// when no sliding window is set (the sliding-window layers keep the band kernels of attention.hip).
+//
+// Replaces the backward of F.scaled_dot_product_attention (TF:integrations/sdpa_attention.py:153-163) under the key-padding
+// mask of TF:masking_utils.py:168-179; the inverse of apply_rotary_pos_emb (TF:models/modernbert/modeling_modernbert.py:188-219)
+// is applied to dq / dk in the epilogues.
+//
+// Structure (both kernels): 8 waves per workgroup, two per SIMD, each wave owning 32 rows of the stationary operand (256 per
+// workgroup) and <= 256 registers, so every MFMA accumulator is an architectural VGPR the VALU reads directly (with the 512-entry
+// budget of one wave per SIMD hipcc selects the AGPR form of every MFMA and pays a v_accvgpr_read per score, measured in ISA:
+// +160 VALU instructions per 64-row tile).  64-row tiles of the streamed operands are staged global -> registers -> LDS one
+// tile ahead into a three-slot ring with a single workgroup barrier per tile; loads are branch-free (clamped rows).  Inside a
+// wave's instruction stream the loop is software pipelined over 32 x 32 score blocks: the score MFMAs of block n+1 are issued
+// next to the exponentials / products / bf16 packing of block n, whose gradient MFMAs follow - on this chip the matrix pipe
+// and the VALU of a SIMD overlap inside one wave's stream, so the overlap is written into it.
+//
+//   dkv  key on the lane: S = Q K^T and dP = dO V^T with -lse and -delta preloaded as the initial accumulators;
+//        dV^T += dO^T P and dK^T += Q^T dS take the score accumulators directly as B operands; dK^T, dV^T of the wave's 32 keys
+//        stay in 64 accumulator registers for the whole sweep over the queries.  Nothing is masked in the loop (see below).
+//   dq   query on the lane: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (K^T by transposed reads of
+//        the same LDS image); also computes delta = rowsum(dO o O) for its rows and publishes it for the dkv kernel.
+//
+// Scores are exponentiated as exp2(c * (q.k) - lse * log2 e) with c = scale * log2 e applied in fp32 on the accumulator
+// (one v_mul per score) - the operands are NOT pre-scaled and re-rounded to bf16.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "attn_common.h"
+
+namespace {
+
+constexpr int kBwdStage = 2 * 8192 + 512;  // two 64 x 64 bf16 images + 128 floats (dkv: -lse / scale and -delta of the 64 rows)
+constexpr int kBwdStages = 3;
+constexpr int kBwdThreads = 512;
+
+__device__ __forceinline__ bf16x8 gload_frag(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// one 16-byte chunk per thread of rows r0 .. r0+63 of a [*, 64] bf16 matrix (512 threads), row index clamped into
+// [0, limit-1]: no branch, no out-of-range address; what the duplicated rows hold is made irrelevant by the caller (a -inf score
+// offset, or a zeroed row)
+__device__ __forceinline__ uint4 gload64x512(const uint16_t* base, int64_t ld, int r0, int limit, int tid) {
+    const int r = min(r0 + (tid >> 3), limit - 1);
+    return *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + (tid & 7) * 8);
+}
+__device__ __forceinline__ void lstore64x512(char* tile, uint4 v, int tid) { *reinterpret_cast<uint4*>(tile + off_R(tid >> 3, tid & 7)) = v; }
+
+// one 32 x 32 score block in place: s -> p = exp2(cm * s), dp -> p * dp   (cm = scale * log2 e, applied in fp32)
+__device__ __forceinline__ void softmax_grad_block(f32x16& s, f32x16& dp, float cm) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(s[i] * cm);
+        s[i] = p;
+        dp[i] = p * dp[i];
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------------------
+// dK, dV.  Workgroup = 256 keys of one (batch, head); wave w owns keys K0 + 32 w .. + 31 (key = MFMA column = lane & 31).
+// LDS slot: Q image (64 rows), dO image, -lse / scale and -delta of the 64 rows.
+// Whatever a padded key computes stays in its own column of dK^T / dV^T: nothing is masked in the loop, the epilogue writes
+// zeros for such keys.  Query rows past the end of the sequence are clamped re-reads whose score offset is -inf (p = 0).
+// -----------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBwdThreads, 2) void attn_bwd_dkv2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                       uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                                       int Smax, int nh, float scale, const float* __restrict__ rope_cos,
+                                                                       const float* __restrict__ rope_sin, int64_t pos_batch_stride,
+                                                                       VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    int kblk, head, b;
+    decode_block((Smax + 255) / 256, nh, kblk, head, b);
+    const int K0 = kblk * 256;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (K0 >= S) return;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
+    const float* lse_bh = lse + sv.stat0;
+    const float* dlt_bh = delta + sv.stat0;
+    const float cm = scale * kLog2e;
+    const float lse_mul = -1.0f / scale;  // accumulators start at -lse / scale: cm * (q.k - lse / scale) = log2 p
+
+    const int krow = K0 + wid * 32 + (lane & 31);
+    bf16x8 kf[4], vf[4];
+    {
+        const int krow_c = min(krow, S - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = gload_frag(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+            vf[s] = gload_frag(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+        }
+    }
+    f32x16 dk[2], dv[2];  // [d block]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
+
+    const int n_tiles = (S + 63) / 64;
+    uint4 qr, gr;
+    float sreg;
+    auto gload = [&](int t) {  // branch-free; tiles past the end reload the last rows and are never used
+        qr = gload64x512(qbase, ld, t * 64, S, tid);
+        gr = gload64x512(dobase, ldo, t * 64, S, tid);
+        const int q = t * 64 + (tid & 63), qc = min(q, S - 1);
+        const float a = lse_bh[qc] * lse_mul, d = -dlt_bh[qc];
+        // rows past S (and rows whose lse is +inf: no visible key) start at -inf and give p = 0
+        sreg = (tid & 64) ? (q < S ? d : 0.f) : (q < S ? a : kNegInf);
+    };
+    auto lstore = [&](int slot) {
+        char* st = smem + slot * kBwdStage;
+        lstore64x512(st, qr, tid);
+        lstore64x512(st + 8192, gr, tid);
+        reinterpret_cast<float*>(st + 16384)[tid & 127] = sreg;  // (threads 128..511 repeat the same values)
+    };
+    // one 32-query x 32-key block: s = Q K^T - lse / scale, dp = dO V^T - delta   (rows = queries, lane = key)
+    auto scores = [&](const char* st, int qb, f32x16& s, f32x16& dp) {
+        const float* nlse = reinterpret_cast<const float*>(st + 16384) + 32 * qb + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 8 * g);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(nlse + 64 + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[4 * g + r] = a[r];
+                dp[4 * g + r] = d[r];
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            s = mfma32(frag_R(st, 32 * qb, s4, lane), kf[s4], s);
+            dp = mfma32(frag_R(st + 8192, 32 * qb, s4, lane), vf[s4], dp);
+        }
+    };
+    // dV^T += dO^T P, dK^T += Q^T dS for that block
+    auto grads = [&](const char* st, int qb, const f32x16& s, const f32x16& dp) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 pf = acc_to_frag(s, sp), dsf = acc_to_frag(dp, sp);
+            const int r0 = 32 * qb + 16 * sp;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = mfma32(frag_T(st + 8192, r0, db, lane), pf, dv[db]);
+                dk[db] = mfma32(frag_T(st, r0, db, lane), dsf, dk[db]);
+            }
+        }
+    };
+
+    // prologue: tile 0 in slot 0, tile 1 in flight, scores of the first block
+    gload(0);
+    lstore(0);
+    gload(1);
+    __syncthreads();
+    f32x16 sA, dpA, sB, dpB;
+    scores(smem, 0, sA, dpA);
+
+    int slot = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int nslot = slot == kBwdStages - 1 ? 0 : slot + 1;
+        const char* st = smem + slot * kBwdStage;
+        const char* nst = smem + nslot * kBwdStage;
+        // tile t+1 (in registers since the previous iteration) goes to its slot, whose last readers finished tile t-2 before the
+        // previous barrier; then the loads of tile t+2 are issued.  One barrier per tile.
+        lstore(nslot);
+        __syncthreads();
+        gload(t + 2);
+        // software pipeline over the 32 x 32 blocks: the score MFMAs of block n+1 are independent of the exponentials /
+        // products / packing of block n, whose gradient MFMAs follow
+        scores(st, 1, sB, dpB);
+        softmax_grad_block(sA, dpA, cm);
+        grads(st, 0, sA, dpA);
+        scores(nst, 0, sA, dpA);  // first block of tile t+1 (past the last tile: computed on stale rows, never used)
+        softmax_grad_block(sB, dpB, cm);
+        grads(st, 1, sB, dpB);
+        slot = nslot;
+    }
+
+    // ---- epilogue: dK = scale * dK^T acc (inverse rotary applied), dV; keys under the padding mask get zeros
+    if (krow < S) {
+        const bool ok = kmask ? kmask[sv.row0 + krow] != 0 : true;
+        const float ks = ok ? scale : 0.f, vs = ok ? 1.f : 0.f;
+        uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
+        uint16_t* dvrow = dkrow + nh * 64;
+        if (!ok) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;  // (a masked column may hold inf / NaN)
+        }
+        if (rope_cos) {
+            const int64_t prow = sv.pos0(b, pos_batch_stride) + krow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 lo4 = {dk[0][4 * g], dk[0][4 * g + 1], dk[0][4 * g + 2], dk[0][4 * g + 3]};
+                f32x4 hi4 = {dk[1][4 * g], dk[1][4 * g + 1], dk[1][4 * g + 2], dk[1][4 * g + 3]};
+                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dk[0][4 * g + r] = lo4[r];
+                    dk[1][4 * g + r] = hi4[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * hh;
+                *reinterpret_cast<uint2*>(dkrow + d) = uint2{pack_bf16x2(dk[db][4 * g] * ks, dk[db][4 * g + 1] * ks),
+                                                             pack_bf16x2(dk[db][4 * g + 2] * ks, dk[db][4 * g + 3] * ks)};
+                *reinterpret_cast<uint2*>(dvrow + d) = uint2{pack_bf16x2(dv[db][4 * g] * vs, dv[db][4 * g + 1] * vs),
+                                                             pack_bf16x2(dv[db][4 * g + 2] * vs, dv[db][4 * g + 3] * vs)};
+            }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------------------
+// dQ and delta.  Workgroup = 256 queries of one (batch, head); wave w owns queries Q0 + 32 w .. + 31 (query = MFMA column).
+// LDS slot: K image (row and transposed reads), V image.
+// Keys under the padding mask (and rows past the end of the sequence) are staged with a ZERO K row: their scores and dS are
+// then finite garbage that multiplies a zero row of K^T in the dQ product - nothing is masked in the loop.
+// -----------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBwdThreads, 2) void attn_bwd_dq2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                                      const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
+                                                                      float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                                      const uint8_t* __restrict__ kmask, int Smax, int nh, float scale,
+                                                                      const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                                                      int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    int qblk, head, b;
+    decode_block((Smax + 255) / 256, nh, qblk, head, b);
+    const int Q0 = qblk * 256;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (Q0 >= S) return;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
+    const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
+    const uint8_t* km = kmask ? kmask + sv.row0 : nullptr;
+    const float cm = scale * kLog2e;
+
+    const int qrow = Q0 + wid * 32 + (lane & 31);
+    const int qrow_c = min(qrow, S - 1);
+    bf16x8 qf[4], dof[4];
+    f32x16 lse_init, dlt_init;
+    {
+        float dlt = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = gload_frag(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+            dof[s] = gload_frag(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+            const bf16x8 of = gload_frag(obase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt += (float)of[j] * (float)dof[s][j];
+        }
+        // delta[q] = sum_d dO[q, d] O[q, d]: the other half of the row sits 32 lanes away.  Published for the dkv kernel.
+        dlt += __shfl_xor(dlt, 32, 64);
+        const int64_t stat = sv.stat0 + qrow_c;
+        if (hh == 0 && qrow < S) delta[stat] = dlt;
+        const float li = -lse[stat] / scale;  // -inf for rows with no visible key -> p = 0
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            lse_init[i] = li;
+            dlt_init[i] = -dlt;
+        }
+    }
+    f32x16 dq[2];  // [d block]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
+
+    const int n_tiles = (S + 63) / 64;
+    uint4 kr, vr;
+    auto gload = [&](int t) {
+        kr = gload64x512(kbase, ld, t * 64, S, tid);
+        vr = gload64x512(vbase, ld, t * 64, S, tid);
+        const int key = t * 64 + (tid >> 3);  // zero the K rows of keys that no query may see
+        const bool ok = key < S && (km ? km[min(key, S - 1)] != 0 : true);
+        if (!ok) kr = uint4{0u, 0u, 0u, 0u};
+    };
+    auto lstore = [&](int slot) {
+        char* st = smem + slot * kBwdStage;
+        lstore64x512(st, kr, tid);
+        lstore64x512(st + 8192, vr, tid);
+    };
+    // one 32-key x 32-query block: s = K Q^T - lse / scale, dp = V dO^T - delta   (rows = keys, lane = query)
+    auto scores = [&](const char* st, int kb, f32x16& s, f32x16& dp) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            s = mfma32(frag_R(st, 32 * kb, s4, lane), qf[s4], s4 == 0 ? lse_init : s);
+            dp = mfma32(frag_R(st + 8192, 32 * kb, s4, lane), dof[s4], s4 == 0 ? dlt_init : dp);
+        }
+    };
+    // dQ^T += K^T dS^T for that block (K^T from the image the row reads use)
+    auto grads = [&](const char* st, int kb, const f32x16& dp) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const bf16x8 dsf = acc_to_frag(dp, sp);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_T(st, 32 * kb + 16 * sp, db, lane), dsf, dq[db]);
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    gload(1);
+    __syncthreads();
+    f32x16 sA, dpA, sB, dpB;
+    scores(smem, 0, sA, dpA);
+
+    int slot = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int nslot = slot == kBwdStages - 1 ? 0 : slot + 1;
+        const char* st = smem + slot * kBwdStage;
+        const char* nst = smem + nslot * kBwdStage;
+        lstore(nslot);
+        __syncthreads();
+        gload(t + 2);
+        scores(st, 1, sB, dpB);
+        softmax_grad_block(sA, dpA, cm);  // dp = dS^T / scale (the scale is applied once, to dQ)
+        grads(st, 0, dpA);
+        scores(nst, 0, sA, dpA);
+        softmax_grad_block(sB, dpB, cm);
+        grads(st, 1, dpB);
+        slot = nslot;
+    }
+
+    if (qrow < S) {
+        uint16_t* drow = dqkv + (sv.row0 + qrow) * ld + head * 64;
+        if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
+            const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 lo4 = {dq[0][4 * g], dq[0][4 * g + 1], dq[0][4 * g + 2], dq[0][4 * g + 3]};
+                f32x4 hi4 = {dq[1][4 * g], dq[1][4 * g + 1], dq[1][4 * g + 2], dq[1][4 * g + 3]};
+                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dq[0][4 * g + r] = lo4[r];
+                    dq[1][4 * g + r] = hi4[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * db + 8 * g + 4 * hh;
+                *reinterpret_cast<uint2*>(drow + d) = uint2{pack_bf16x2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale),
+                                                            pack_bf16x2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale)};
+            }
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------------------------------------------
+// dK, dV, hand-scheduled: ONE wave per SIMD with the whole 512-entry register file, wave w owns keys K0 + 64 w .. + 63 (two
+// 32-key column blocks kb), workgroup = 4 waves = 256 keys.
+//
+// With the 512-entry budget hipcc selects the AGPR form of every MFMA it generates, and the VALU cannot read AGPRs.  So the
+// products whose results the VALU consumes (S and dP) are issued as inline-asm MFMAs with VGPR destinations (their B operands,
+// the wave's K / V fragments, live in AGPRs: 64 registers the VGPR file does not have to hold), while the accumulating products
+// (dV^T, dK^T: 128 AGPRs) stay compiler MFMAs.  An asm MFMA's result is first read one pipeline step (hundreds of cycles) after
+// it was issued, behind a sched_barrier, which covers the MFMA -> VALU hazard the compiler does not pad for an asm statement.
+//
+// Schedule: the tile's four 32 x 32 blocks u = (qb, kb) are software pipelined in ONE instruction stream, every instruction
+// placed by hand at chunk granularity (sched_barrier(0) between chunks):
+//     step k:  [8 score MFMAs of block k+1, each followed by two (mul, exp) pairs of block k]      <- 16 exponentials
+//              [8 gradient MFMAs of block k, each preceded by the products / bf16 packs it needs]
+// LDS fragments are register-resident per 32-query block and shared by its two key blocks; a fragment register is reloaded for
+// the NEXT query block right behind the last MFMA that read it, a full step before its next use, so no MFMA waits for LDS.
+// Tiles are staged global -> registers -> LDS into a four-slot ring (one barrier per tile); the loop is unrolled over the ring
+// so every LDS address is a per-lane base plus an immediate.
+// -----------------------------------------------------------------------------------------------------------------------------
+constexpr int kSlots3 = 4;
+
+#ifndef CM3P_ABL
+#define CM3P_ABL 0  // timing-only ablation builds (tools/ubench/attn_bwd_ablate.sh): 1 no barrier, 2 no tile staging, 4 no fragment reloads, 8 no exponentials
+#endif
+#define CM3P_SB() __builtin_amdgcn_sched_barrier(0)
+#if CM3P_ABL & 16  // timing only: every score MFMA starts from the row constants (no accumulate chain)
+#define SC_ACC(d, a, b, c) mfma_vc(d, a, b, c)
+#else
+#define SC_ACC(d, a, b, c) mfma_va(d, a, b)
+#endif
+
+// D (VGPRs) = A (VGPRs) * B (AGPRs) + C (VGPRs); D never overlaps an input
+__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+// D += A * B (same registers)
+__device__ __forceinline__ void mfma_va(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void exp2_pair(f32x16& s, int i, float cm) {
+    if constexpr ((CM3P_ABL & 8) != 0) return;
+    s[i] = __builtin_amdgcn_exp2f(s[i] * cm);
+    s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1] * cm);
+}
+__device__ __forceinline__ bf16x8 ld_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 ld_fragT(const char* lo, const char* hi) { return cat_bf16x4(lds_read_tr16(lo), lds_read_tr16(hi)); }
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                               int Smax, int nh, float scale, const float* __restrict__ rope_cos,
+                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    int kblk, head, b;
+    decode_block((Smax + 255) / 256, nh, kblk, head, b);
+    const int K0 = kblk * 256;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (K0 >= S) return;
+    const int k0 = K0 + wid * 64;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
+    const float* lse_bh = lse + sv.stat0;
+    const float* dlt_bh = delta + sv.stat0;
+    const float cm = scale * kLog2e;
+    const float lse_mul = -1.0f / scale;  // accumulators start at -lse / scale: cm * (q.k - lse / scale) = log2 p
+
+    bf16x8 kf[2][4], vf[2][4];  // B operands of the asm MFMAs ("a" constraint: they live in AGPRs)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow_c = min(k0 + 32 * kb + (lane & 31), S - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[kb][s] = gload_frag(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+            vf[kb][s] = gload_frag(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+        }
+    }
+    f32x16 dk[2][2], dv[2][2];  // [d block][key block]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;
+
+    // per-lane LDS byte offsets inside a slot; everything else is an immediate
+    const int l31 = lane & 31, g4 = lane >> 4, i16 = lane & 15;
+    int oR[4], oTlo[2], oThi[2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) oR[s4] = off_R(l31, 2 * s4 + hh);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int row = 4 * hh + (i16 >> 2), col = 32 * db + 16 * (g4 & 1) + 4 * (i16 & 3);
+        oTlo[db] = off_T(row, col);
+        oThi[db] = off_T(row + 8, col);
+    }
+    const int oI = 16384 + 16 * hh;
+
+    const int n_tiles = (S + 63) / 64;
+    // Staging registers: TWO sets (tiles of even / odd index), so a tile's global loads are in flight for two tile periods before
+    // their first use in the LDS stores.  Plain named scalars on purpose: a struct or an indexed array ends up in scratch.
+    uint4 aq0, aq1, ag0, ag1, bq0, bq1, bg0, bg1;
+    float araw = 0.f, braw = 0.f;  // raw lse (threads with tid & 64 == 0) or delta of row t * 64 + (tid & 63)
+    bool aok = false, bok = false;
+    const int srow = tid >> 3, schunk = (tid & 7) * 8;
+    const float* stat_src = (tid & 64) ? dlt_bh : lse_bh;
+    const int oW0 = off_R(srow, tid & 7), oW1 = off_R(srow + 32, tid & 7);
+    // Branch-free, and NOTHING in a load block consumes a loaded value: the first use of every staging register is in the store
+    // block (an arithmetic instruction on a fresh load makes the compiler wait for the whole memory round trip right there,
+    // every tile: measured 30 % of this kernel).  Tiles past the end reload the last rows with a -inf score offset (p = 0).
+#define CM3P_GLOAD(P, t_)                                                                          \
+    do {                                                                                            \
+        const int t__ = (t_);                                                                       \
+        const int r0 = min(t__ * 64 + srow, S - 1), r1 = min(t__ * 64 + 32 + srow, S - 1);           \
+        P##q0 = *reinterpret_cast<const uint4*>(qbase + (int64_t)r0 * ld + schunk);                 \
+        P##q1 = *reinterpret_cast<const uint4*>(qbase + (int64_t)r1 * ld + schunk);                 \
+        P##g0 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r0 * ldo + schunk);               \
+        P##g1 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r1 * ldo + schunk);               \
+        const int q__ = t__ * 64 + (tid & 63);                                                      \
+        P##raw = stat_src[min(q__, S - 1)];                                                         \
+        P##ok = q__ < S;                                                                            \
+    } while (0)
+    // -lse / scale (rows past S, and rows whose lse is +inf because they see no key, start at -inf: p = 0) and -delta
+#define CM3P_LSTORE(P, st_)                                                                                          \
+    do {                                                                                                              \
+        char* st__ = (st_);                                                                                           \
+        *reinterpret_cast<uint4*>(st__ + oW0) = P##q0;                                                                \
+        *reinterpret_cast<uint4*>(st__ + oW1) = P##q1;                                                                \
+        *reinterpret_cast<uint4*>(st__ + 8192 + oW0) = P##g0;                                                         \
+        *reinterpret_cast<uint4*>(st__ + 8192 + oW1) = P##g1;                                                         \
+        const float sreg__ = (tid & 64) ? (P##ok ? -P##raw : 0.f) : (P##ok ? P##raw * lse_mul : kNegInf);             \
+        reinterpret_cast<float*>(st__ + 16384)[tid & 127] = sreg__; /* (threads 128..255 repeat the same values) */   \
+    } while (0)
+
+    // register-resident LDS fragments of the current 32-query block
+    bf16x8 Qf[4], Gf[4];     // rows of Q / dO (A operands of the score products)
+    bf16x8 gT[2][2], qT[2][2];  // [sp][db]: dO^T / Q^T (A operands of the gradient products)
+    f32x16 isv, idv;         // -lse / scale and -delta of the block's 32 rows, in accumulator layout
+    auto load_init = [&](const char* sq, f32x16& v, int which, int half) {  // `half` of the 16 values: two 16-byte reads
+#pragma unroll
+        for (int g = 2 * half; g < 2 * half + 2; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sq + oI + 256 * which + 32 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * g + r] = a[r];
+        }
+    };
+    // sq = slot base + 4096 * qb (row fragments), 128 * qb extra for the init floats is folded in by the caller via sqi
+    auto loadS_all = [&](const char* sq, const char* sqi) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            Qf[s4] = ld_frag(sq + oR[s4]);
+            Gf[s4] = ld_frag(sq + 8192 + oR[s4]);
+        }
+        load_init(sqi, isv, 0, 0);
+        load_init(sqi, isv, 0, 1);
+        load_init(sqi, idv, 1, 0);
+        load_init(sqi, idv, 1, 1);
+    };
+    auto loadG_one = [&](const char* sq, int sp, int db, int which) {  // which: 0 = dO^T, 1 = Q^T
+        const char* base = sq + (which == 0 ? 8192 : 0) + 2048 * sp;
+        const bf16x8 f = ld_fragT(base + oTlo[db], base + oThi[db]);
+        if (which == 0) gT[sp][db] = f;
+        else qT[sp][db] = f;
+    };
+
+    // One pipeline step: scores of block Y (key block KBY; its query block's fragments are resident) next to the exponentials
+    // of block X, then the gradient products of block X (key block KBX).  KBY == 1: Y is the last user of the resident row
+    // fragments, which are reloaded for the next query block from `nS` / `nSi` right behind the MFMAs that read them.
+    // KBX == 1: X is the last user of the resident transposed fragments, reloaded from `nG` the same way.
+    auto step = [&](auto kbx_c, auto kby_c, f32x16& Xs, f32x16& Xdp, f32x16& Ys, f32x16& Ydp, const char* nS, const char* nSi,
+                    const char* nG) {
+        constexpr int KBX = decltype(kbx_c)::value, KBY = decltype(kby_c)::value;
+        CM3P_SB();
+        mfma_vc(Ys, Qf[0], kf[KBY][0], isv);
+        exp2_pair(Xs, 0, cm);
+        CM3P_SB();
+        mfma_vc(Ydp, Gf[0], vf[KBY][0], idv);
+        exp2_pair(Xs, 2, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
+            Qf[0] = ld_frag(nS + oR[0]);
+            Gf[0] = ld_frag(nS + 8192 + oR[0]);
+            load_init(nSi, isv, 0, 0);
+        }
+        CM3P_SB();
+        SC_ACC(Ys, Qf[1], kf[KBY][1], isv);
+        exp2_pair(Xs, 4, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
+            load_init(nSi, isv, 0, 1);
+            Qf[1] = ld_frag(nS + oR[1]);
+        }
+        CM3P_SB();
+        SC_ACC(Ydp, Gf[1], vf[KBY][1], idv);
+        exp2_pair(Xs, 6, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
+            Gf[1] = ld_frag(nS + 8192 + oR[1]);
+            load_init(nSi, idv, 1, 0);
+        }
+        CM3P_SB();
+        SC_ACC(Ys, Qf[2], kf[KBY][2], isv);
+        exp2_pair(Xs, 8, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
+            Qf[2] = ld_frag(nS + oR[2]);
+            load_init(nSi, idv, 1, 1);
+        }
+        CM3P_SB();
+        SC_ACC(Ydp, Gf[2], vf[KBY][2], idv);
+        exp2_pair(Xs, 10, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[2] = ld_frag(nS + 8192 + oR[2]);
+        CM3P_SB();
+        SC_ACC(Ys, Qf[3], kf[KBY][3], isv);
+        exp2_pair(Xs, 12, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Qf[3] = ld_frag(nS + oR[3]);
+        CM3P_SB();
+        SC_ACC(Ydp, Gf[3], vf[KBY][3], idv);
+        exp2_pair(Xs, 14, cm);
+        if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[3] = ld_frag(nS + 8192 + oR[3]);
+        CM3P_SB();
+        // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS
+        const bf16x8 pf0 = acc_to_frag(Xs, 0);
+        dv[0][KBX] = mfma32(gT[0][0], pf0, dv[0][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xdp[i] *= Xs[i];
+        CM3P_SB();
+        dv[1][KBX] = mfma32(gT[0][1], pf0, dv[1][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 0);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) Xdp[i] *= Xs[i];
+        const bf16x8 ds0 = acc_to_frag(Xdp, 0);
+        CM3P_SB();
+        dk[0][KBX] = mfma32(qT[0][0], ds0, dk[0][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 1);
+        const bf16x8 pf1 = acc_to_frag(Xs, 1);
+        CM3P_SB();
+        dk[1][KBX] = mfma32(qT[0][1], ds0, dk[1][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 1);
+#pragma unroll
+        for (int i = 8; i < 12; ++i) Xdp[i] *= Xs[i];
+        CM3P_SB();
+        dv[0][KBX] = mfma32(gT[1][0], pf1, dv[0][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 0, 0);
+#pragma unroll
+        for (int i = 12; i < 16; ++i) Xdp[i] *= Xs[i];
+        const bf16x8 ds1 = acc_to_frag(Xdp, 1);
+        CM3P_SB();
+        dv[1][KBX] = mfma32(gT[1][1], pf1, dv[1][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 1, 0);
+        CM3P_SB();
+        dk[0][KBX] = mfma32(qT[1][0], ds1, dk[0][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 0, 1);
+        CM3P_SB();
+        dk[1][KBX] = mfma32(qT[1][1], ds1, dk[1][KBX]);
+        if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 1, 1);
+        CM3P_SB();
+    };
+
+    f32x16 sA, dpA, sB, dpB;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // one tile (ring slot SL): publish tile t+1, sync, start the loads of tile t+2, then the four steps
+    auto tile = [&](auto slot_c, int t) {
+        constexpr int SL = decltype(slot_c)::value, NS = (SL + 1) % kSlots3;
+        const char* st = smem + SL * kBwdStage;
+        char* nst = smem + NS * kBwdStage;
+        // tile t+1 sits in the staging set of ITS parity since the top of tile t-1; tile t+3 takes the set over
+        // (the slot's last readers finished tile t-3 before the previous barrier)
+        if constexpr (!(CM3P_ABL & 2)) {
+            if constexpr (SL & 1) CM3P_LSTORE(a, nst);
+            else CM3P_LSTORE(b, nst);
+        }
+        if constexpr (!(CM3P_ABL & 1)) __syncthreads();
+        if constexpr (!(CM3P_ABL & 2)) {
+            if constexpr (SL & 1) CM3P_GLOAD(a, t + 3);
+            else CM3P_GLOAD(b, t + 3);
+        }
+        step(I0{}, I1{}, sA, dpA, sB, dpB, st + 4096, st + 128, nullptr);   // X = (qb0, kb0), Y = (qb0, kb1); row fragments -> qb1
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, st + 4096);    // X = (qb0, kb1), Y = (qb1, kb0); transposed -> qb1
+        step(I0{}, I1{}, sA, dpA, sB, dpB, nst, nst, nullptr);              // X = (qb1, kb0), Y = (qb1, kb1); row fragments -> next tile
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, nst);          // X = (qb1, kb1), Y = next tile's (qb0, kb0)
+    };
+
+    // prologue: tile 0 in slot 0, tile 1 in flight, fragments of (tile 0, qb0), scores of its first block
+    CM3P_GLOAD(a, 0);
+    CM3P_LSTORE(a, smem);
+    CM3P_GLOAD(b, 1);  // odd tiles: set b
+    CM3P_GLOAD(a, 2);  // even tiles: set a
+    __syncthreads();
+    loadS_all(smem, smem);
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            loadG_one(smem, sp, db, 0);
+            loadG_one(smem, sp, db, 1);
+        }
+    mfma_vc(sA, Qf[0], kf[0][0], isv);
+    mfma_vc(dpA, Gf[0], vf[0][0], idv);
+#pragma unroll
+    for (int s4 = 1; s4 < 4; ++s4) {
+        mfma_va(sA, Qf[s4], kf[0][s4]);
+        mfma_va(dpA, Gf[s4], vf[0][s4]);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the only place a result is read right behind its asm MFMA chain)
+    CM3P_SB();
+
+    // (tiles past the last one - when the tile count is not a multiple of the ring size - re-read the last rows with a -inf
+    //  score offset and add exact zeros: no exit edge inside the unrolled ring, so the accumulators never change registers)
+    for (int t = 0; t < n_tiles; t += kSlots3) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
+        tile(std::integral_constant<int, 2>{}, t + 2);
+        tile(std::integral_constant<int, 3>{}, t + 3);
+    }
+
+    // ---- epilogue: dK = scale * dK^T acc (inverse rotary applied), dV; keys under the padding mask get zeros
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow = k0 + 32 * kb + (lane & 31);
+        if (krow < S) {
+            const bool ok = kmask ? kmask[sv.row0 + krow] != 0 : true;
+            const float ks = ok ? scale : 0.f, vs = ok ? 1.f : 0.f;
+            uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
+            uint16_t* dvrow = dkrow + nh * 64;
+            if (!ok) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;  // (a masked column may hold inf / NaN)
+            }
+            if (rope_cos) {
+                const int64_t prow = sv.pos0(b, pos_batch_stride) + krow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 lo4 = {dk[0][kb][4 * g], dk[0][kb][4 * g + 1], dk[0][kb][4 * g + 2], dk[0][kb][4 * g + 3]};
+                    f32x4 hi4 = {dk[1][kb][4 * g], dk[1][kb][4 * g + 1], dk[1][kb][4 * g + 2], dk[1][kb][4 * g + 3]};
+                    rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dk[0][kb][4 * g + r] = lo4[r];
+                        dk[1][kb][4 * g + r] = hi4[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * db + 8 * g + 4 * hh;
+                    *reinterpret_cast<uint2*>(dkrow + d) = uint2{pack_bf16x2(dk[db][kb][4 * g] * ks, dk[db][kb][4 * g + 1] * ks),
+                                                                 pack_bf16x2(dk[db][kb][4 * g + 2] * ks, dk[db][kb][4 * g + 3] * ks)};
+                    *reinterpret_cast<uint2*>(dvrow + d) = uint2{pack_bf16x2(dv[db][kb][4 * g] * vs, dv[db][kb][4 * g + 1] * vs),
+                                                                 pack_bf16x2(dv[db][kb][4 * g + 2] * vs, dv[db][kb][4 * g + 3] * vs)};
+                }
+        }
+    }
+}
+
+}  // namespace
+
+// Launcher used by attention.hip's cm3p_attn_bwd / cm3p_attn_bwd_varlen for window < 0.
+int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                const uint8_t* key_mask, int B, int S, int nh, float scale, const float* cos_tab, const float* sin_tab,
+                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, hipStream_t s) {
+    const VarLen vl{cu_seqlens, total};
+    const dim3 grid(((S + 255) / 256) * nh * B);  // 1-D: decode_block() maps it XCD-aware
+    const size_t lds = kBwdStages * kBwdStage;
+    if (stages & CM3P_ATTN_BWD_DQ) {
+        attn_bwd_dq2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
+                                                   key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+    }
+    if (stages & CM3P_ATTN_BWD_DKV) {
+        static const bool v2 = [] { const char* e = getenv("CM3P_ATTN_BWD_DKV"); return e && e[0] == '2'; }();  // kernel experiments only
+        if (v2)
+            attn_bwd_dkv2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S,
+                                                                nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        else
+            attn_bwd_dkv3_kernel<<<grid, 256, kSlots3 * kBwdStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                                                                        key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+    }
+    return CM3P_OK;
+}
