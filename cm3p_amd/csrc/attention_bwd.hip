@@ -721,6 +721,295 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------------------
+// dQ and delta, hand-scheduled like attn_bwd_dkv3_kernel: ONE wave per SIMD, wave w owns queries Q0 + 64 w .. + 63 (two 32-query
+// column blocks qb), workgroup = 4 waves = 256 queries; the blocks u = (kb, qb) of a 64-key tile are software pipelined in one
+// hand-placed instruction stream.
+//   scores    S^T = K Q^T (asm MFMA from zero, VGPR result; -lse log2 e is added by the v_fma that also applies scale log2 e)
+//             dP^T = V dO^T - delta (asm MFMA, initial accumulator = -delta of the lane's query), Q / dO fragments in AGPRs
+//   gradient  dQ^T += K^T dS^T (compiler MFMAs, AGPR accumulators), K^T by transposed reads of the K image
+// K / V row fragments and K^T fragments are register-resident per 32-key block, shared by its two query blocks and reloaded for
+// the next key block right behind the last MFMA that read them.  Keys under the padding mask (and rows past the end of the
+// sequence) are staged with a ZERO K row, so nothing is masked in the loop.
+// -----------------------------------------------------------------------------------------------------------------------------
+constexpr int kDq3Stage = 2 * 8192;
+
+// D (VGPRs) = A (VGPRs) * B (AGPRs), from zero
+__device__ __forceinline__ void mfma_v0(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void exp2_fma_pair(f32x16& s, int i, float cm, float nl) {
+    s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], cm, nl));
+    s[i + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i + 1], cm, nl));
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                              const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                              const uint8_t* __restrict__ kmask, int Smax, int nh, float scale,
+                                                              const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                                              int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    int qblk, head, b;
+    decode_block((Smax + 255) / 256, nh, qblk, head, b);
+    const int Q0 = qblk * 256;
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    if (Q0 >= S) return;
+    const int q0 = Q0 + wid * 64;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
+    const uint16_t* kbase = qbase + nh * 64;
+    const uint16_t* vbase = qbase + 2 * nh * 64;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
+    const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
+    const float cm = scale * kLog2e;
+
+    bf16x8 qf[2][4], dof[2][4];  // B operands of the asm MFMAs ("a" constraint: they live in AGPRs)
+    f32x16 dlt_init[2];
+    float nl2[2];  // -lse * log2(e) of the lane's queries (-inf for rows with no visible key: p = 0)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + 32 * qb + (lane & 31);
+        const int qrow_c = min(qrow, S - 1);
+        float dlt = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[qb][s] = gload_frag(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
+            dof[qb][s] = gload_frag(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+            const bf16x8 of = gload_frag(obase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dlt += (float)of[j] * (float)dof[qb][s][j];
+        }
+        // delta[q] = sum_d dO[q, d] O[q, d]: the other half of the row sits 32 lanes away.  Published for the dkv kernel.
+        dlt += __shfl_xor(dlt, 32, 64);
+        const int64_t stat = sv.stat0 + qrow_c;
+        if (hh == 0 && qrow < S) delta[stat] = dlt;
+        nl2[qb] = -lse[stat] * kLog2e;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dlt_init[qb][i] = -dlt;
+        // dO fed the delta sum on the VALU, so the compiler holds it in VGPRs and would copy it into an AGPR right in front of
+        // every asm MFMA (v_accvgpr_write -> MFMA operand: a hazard nobody pads for an asm statement - stale operands, NaN).
+        // Re-define both operand sets HERE as AGPR values; from now on only "a" operands read them.
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            asm volatile("" : "+a"(qf[qb][s]));
+            asm volatile("" : "+a"(dof[qb][s]));
+        }
+    }
+    f32x16 dq[2][2];  // [d block][query block]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq[db][qb][i] = 0.f;
+
+    // per-lane LDS byte offsets inside a slot; everything else is an immediate
+    const int l31 = lane & 31, g4 = lane >> 4, i16 = lane & 15;
+    int oR[4], oTlo[2], oThi[2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) oR[s4] = off_R(l31, 2 * s4 + hh);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int row = 4 * hh + (i16 >> 2), col = 32 * db + 16 * (g4 & 1) + 4 * (i16 & 3);
+        oTlo[db] = off_T(row, col);
+        oThi[db] = off_T(row + 8, col);
+    }
+
+    const int n_tiles = (S + 63) / 64;
+    // two staging sets (even / odd tiles), plain named scalars (see attn_bwd_dkv3_kernel)
+    uint4 ak0, ak1, av0, av1, bk0, bk1, bv0, bv1;
+    uint8_t am0 = 0, am1 = 0, bm0 = 0, bm1 = 0;
+    bool aok0 = false, aok1 = false, bok0 = false, bok1 = false;
+    const int srow = tid >> 3, schunk = (tid & 7) * 8;
+    const int oW0 = off_R(srow, tid & 7), oW1 = off_R(srow + 32, tid & 7);
+    const uint8_t* km = kmask ? kmask + sv.row0 : nullptr;
+#define CM3P_GLOADQ(P, t_)                                                                     \
+    do {                                                                                        \
+        const int t__ = (t_);                                                                   \
+        const int r0 = min(t__ * 64 + srow, S - 1), r1 = min(t__ * 64 + 32 + srow, S - 1);       \
+        P##k0 = *reinterpret_cast<const uint4*>(kbase + (int64_t)r0 * ld + schunk);             \
+        P##k1 = *reinterpret_cast<const uint4*>(kbase + (int64_t)r1 * ld + schunk);             \
+        P##v0 = *reinterpret_cast<const uint4*>(vbase + (int64_t)r0 * ld + schunk);             \
+        P##v1 = *reinterpret_cast<const uint4*>(vbase + (int64_t)r1 * ld + schunk);             \
+        if (km) {                                                                               \
+            P##m0 = km[r0];                                                                     \
+            P##m1 = km[r1];                                                                     \
+        }                                                                                       \
+        P##ok0 = t__ * 64 + srow < S;                                                           \
+        P##ok1 = t__ * 64 + 32 + srow < S;                                                      \
+    } while (0)
+    // the K rows of keys that no query may see are stored as zeros
+#define CM3P_LSTOREQ(P, st_)                                                                    \
+    do {                                                                                        \
+        char* st__ = (st_);                                                                     \
+        const bool z0 = !(P##ok0 && (km == nullptr || P##m0 != 0)), z1 = !(P##ok1 && (km == nullptr || P##m1 != 0)); \
+        *reinterpret_cast<uint4*>(st__ + oW0) = z0 ? uint4{0u, 0u, 0u, 0u} : P##k0;             \
+        *reinterpret_cast<uint4*>(st__ + oW1) = z1 ? uint4{0u, 0u, 0u, 0u} : P##k1;             \
+        *reinterpret_cast<uint4*>(st__ + 8192 + oW0) = P##v0;                                   \
+        *reinterpret_cast<uint4*>(st__ + 8192 + oW1) = P##v1;                                   \
+    } while (0)
+
+    // register-resident LDS fragments of the current 32-key block
+    bf16x8 Kf[4], Vf[4];  // rows of K / V (A operands of the score products)
+    bf16x8 kT[2][2];      // [sp][db]: K^T (A operands of the gradient product)
+    auto loadT_one = [&](const char* sq, int sp, int db) {
+        const char* base = sq + 2048 * sp;
+        kT[sp][db] = ld_fragT(base + oTlo[db], base + oThi[db]);
+    };
+
+    // One pipeline step: scores of block Y (query block QBY; its key block's fragments are resident) next to the exponentials of
+    // block X, then the gradient product of block X (query block QBX).  QBY == 1: Y is the last user of the resident row
+    // fragments, reloaded for the next key block from `nS`.  QBX == 1: X is the last user of the K^T fragments, reloaded from `nG`.
+    auto step = [&](auto qbx_c, auto qby_c, f32x16& Xs, f32x16& Xdp, f32x16& Ys, f32x16& Ydp, const char* nS, const char* nG) {
+        constexpr int QBX = decltype(qbx_c)::value, QBY = decltype(qby_c)::value;
+        const float nl = nl2[QBX];
+        CM3P_SB();
+        mfma_v0(Ys, Kf[0], qf[QBY][0]);
+        exp2_fma_pair(Xs, 0, cm, nl);
+        CM3P_SB();
+        mfma_vc(Ydp, Vf[0], dof[QBY][0], dlt_init[QBY]);
+        exp2_fma_pair(Xs, 2, cm, nl);
+        if constexpr (QBY == 1) {
+            Kf[0] = ld_frag(nS + oR[0]);
+            Vf[0] = ld_frag(nS + 8192 + oR[0]);
+        }
+        CM3P_SB();
+        mfma_va(Ys, Kf[1], qf[QBY][1]);
+        exp2_fma_pair(Xs, 4, cm, nl);
+        if constexpr (QBY == 1) Kf[1] = ld_frag(nS + oR[1]);
+        CM3P_SB();
+        mfma_va(Ydp, Vf[1], dof[QBY][1]);
+        exp2_fma_pair(Xs, 6, cm, nl);
+        if constexpr (QBY == 1) Vf[1] = ld_frag(nS + 8192 + oR[1]);
+        CM3P_SB();
+        mfma_va(Ys, Kf[2], qf[QBY][2]);
+        exp2_fma_pair(Xs, 8, cm, nl);
+        if constexpr (QBY == 1) Kf[2] = ld_frag(nS + oR[2]);
+        CM3P_SB();
+        mfma_va(Ydp, Vf[2], dof[QBY][2]);
+        exp2_fma_pair(Xs, 10, cm, nl);
+        if constexpr (QBY == 1) Vf[2] = ld_frag(nS + 8192 + oR[2]);
+        CM3P_SB();
+        mfma_va(Ys, Kf[3], qf[QBY][3]);
+        exp2_fma_pair(Xs, 12, cm, nl);
+        if constexpr (QBY == 1) Kf[3] = ld_frag(nS + oR[3]);
+        CM3P_SB();
+        mfma_va(Ydp, Vf[3], dof[QBY][3]);
+        exp2_fma_pair(Xs, 14, cm, nl);
+        if constexpr (QBY == 1) Vf[3] = ld_frag(nS + 8192 + oR[3]);
+        CM3P_SB();
+        // ---- gradient product of X: dQ^T += K^T dS^T with dS^T = P^T o (dP^T - delta) (the 1/sqrt(d) scale is applied once, to dQ)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Xdp[i] *= Xs[i];
+        const bf16x8 ds0 = acc_to_frag(Xdp, 0);
+        dq[0][QBX] = mfma32(kT[0][0], ds0, dq[0][QBX]);
+        if constexpr (QBX == 1) loadT_one(nG, 0, 0);
+#pragma unroll
+        for (int i = 8; i < 12; ++i) Xdp[i] *= Xs[i];
+        CM3P_SB();
+        dq[1][QBX] = mfma32(kT[0][1], ds0, dq[1][QBX]);
+        if constexpr (QBX == 1) loadT_one(nG, 0, 1);
+#pragma unroll
+        for (int i = 12; i < 16; ++i) Xdp[i] *= Xs[i];
+        const bf16x8 ds1 = acc_to_frag(Xdp, 1);
+        CM3P_SB();
+        dq[0][QBX] = mfma32(kT[1][0], ds1, dq[0][QBX]);
+        if constexpr (QBX == 1) loadT_one(nG, 1, 0);
+        CM3P_SB();
+        dq[1][QBX] = mfma32(kT[1][1], ds1, dq[1][QBX]);
+        if constexpr (QBX == 1) loadT_one(nG, 1, 1);
+        CM3P_SB();
+    };
+
+    f32x16 sA, dpA, sB, dpB;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto tile = [&](auto slot_c, int t) {
+        constexpr int SL = decltype(slot_c)::value, NS = (SL + 1) % kSlots3;
+        const char* st = smem + SL * kDq3Stage;
+        char* nst = smem + NS * kDq3Stage;
+        // tile t+1 sits in the staging set of its parity since the top of tile t-1; tile t+3 takes the set over
+        if constexpr (SL & 1) CM3P_LSTOREQ(a, nst);
+        else CM3P_LSTOREQ(b, nst);
+        __syncthreads();
+        if constexpr (SL & 1) CM3P_GLOADQ(a, t + 3);
+        else CM3P_GLOADQ(b, t + 3);
+        step(I0{}, I1{}, sA, dpA, sB, dpB, st + 4096, nullptr);  // X = (kb0, qb0), Y = (kb0, qb1); row fragments -> kb1
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, st + 4096);  // X = (kb0, qb1), Y = (kb1, qb0); K^T fragments -> kb1
+        step(I0{}, I1{}, sA, dpA, sB, dpB, nst, nullptr);        // X = (kb1, qb0), Y = (kb1, qb1); row fragments -> next tile
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nst);        // X = (kb1, qb1), Y = next tile's (kb0, qb0)
+    };
+
+    // prologue: tile 0 in slot 0, tiles 1 and 2 in flight, fragments of (tile 0, kb0), scores of its first block
+    CM3P_GLOADQ(a, 0);
+    CM3P_LSTOREQ(a, smem);
+    CM3P_GLOADQ(b, 1);
+    CM3P_GLOADQ(a, 2);
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        Kf[s4] = ld_frag(smem + oR[s4]);
+        Vf[s4] = ld_frag(smem + 8192 + oR[s4]);
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) loadT_one(smem, sp, db);
+    mfma_v0(sA, Kf[0], qf[0][0]);
+    mfma_vc(dpA, Vf[0], dof[0][0], dlt_init[0]);
+#pragma unroll
+    for (int s4 = 1; s4 < 4; ++s4) {
+        mfma_va(sA, Kf[s4], qf[0][s4]);
+        mfma_va(dpA, Vf[s4], dof[0][s4]);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the only place a result is read right behind its asm MFMA chain)
+    CM3P_SB();
+
+    // (tiles past the last one stage zero K rows and add exact zeros)
+    for (int t = 0; t < n_tiles; t += kSlots3) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
+        tile(std::integral_constant<int, 2>{}, t + 2);
+        tile(std::integral_constant<int, 3>{}, t + 3);
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0 + 32 * qb + (lane & 31);
+        if (qrow < S) {
+            uint16_t* drow = dqkv + (sv.row0 + qrow) * ld + head * 64;
+            if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
+                const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 lo4 = {dq[0][qb][4 * g], dq[0][qb][4 * g + 1], dq[0][qb][4 * g + 2], dq[0][qb][4 * g + 3]};
+                    f32x4 hi4 = {dq[1][qb][4 * g], dq[1][qb][4 * g + 1], dq[1][qb][4 * g + 2], dq[1][qb][4 * g + 3]};
+                    rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dq[0][qb][4 * g + r] = lo4[r];
+                        dq[1][qb][4 * g + r] = hi4[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * db + 8 * g + 4 * hh;
+                    *reinterpret_cast<uint2*>(drow + d) =
+                        uint2{pack_bf16x2(dq[db][qb][4 * g] * scale, dq[db][qb][4 * g + 1] * scale),
+                              pack_bf16x2(dq[db][qb][4 * g + 2] * scale, dq[db][qb][4 * g + 3] * scale)};
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // Launcher used by attention.hip's cm3p_attn_bwd / cm3p_attn_bwd_varlen for window < 0.
@@ -731,8 +1020,14 @@ int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* do
     const dim3 grid(((S + 255) / 256) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     const size_t lds = kBwdStages * kBwdStage;
     if (stages & CM3P_ATTN_BWD_DQ) {
-        attn_bwd_dq2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
-                                                   key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        static const bool v2 = [] { const char* e = getenv("CM3P_ATTN_BWD_DQ"); return e && e[0] == '2'; }();  // kernel experiments only
+        if (v2)
+            attn_bwd_dq2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta,
+                                                               (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        else
+            attn_bwd_dq3_kernel<<<grid, 256, kSlots3 * kDq3Stage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta,
+                                                                       (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab,
+                                                                       pos_batch_stride, vl);
         if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
     if (stages & CM3P_ATTN_BWD_DKV) {
