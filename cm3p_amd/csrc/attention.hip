@@ -119,20 +119,22 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
     const int t_lo = klo / 64, t_hi = khi / 64;
 
     TileRegs64 kr, vr;
-    uint8_t mreg = 0;
+    uint8_t mraw = 1;
+    bool mok = false;
+    // (nothing here consumes a loaded value - see attn_bwd_dkv_kernel; the mask byte is judged in lstore())
     auto gload = [&](int t) {
         gload64(kr, kbase, ld, t * 64, S, tid);
         gload64(vr, vbase, ld, t * 64, S, tid);
-        if (tid < 64) {
-            const int key = t * 64 + tid;
-            mreg = key < S ? (kmask ? kmask[sv.row0 + key] : (uint8_t)1) : (uint8_t)0;
-        }
+        const int key = t * 64 + (tid & 63);
+        mok = key < S;
+        if (kmask) mraw = kmask[sv.row0 + min(max(key, 0), S - 1)];
     };
     auto lstore = [&](int stage) {
         char* st = smem + stage * kFwdStage;
         lstore64_R(st, kr, tid);
         lstore64_R(st + 8192, vr, tid);
         if (tid < 64) {
+            const uint8_t mreg = mok ? mraw : (uint8_t)0;
             reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
             const unsigned long long valid = __ballot(mreg != 0);
             if (tid == 0) *reinterpret_cast<int*>(st + 16448) = (valid == ~0ull) ? 1 : 0;
@@ -318,20 +320,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     }
 
     TileRegs64 kr, vr;
-    uint8_t mreg = 0;
+    uint8_t mraw = 1;
+    bool mok = false;
+    // (nothing here consumes a loaded value - see attn_bwd_dkv_kernel; the mask byte is judged in lstore())
     auto gload = [&](int t) {
         gload64(kr, kbase, ld, t * 64, S, tid);
         gload64(vr, vbase, ld, t * 64, S, tid);
-        if (tid < 64) {
-            const int key = t * 64 + tid;
-            mreg = key < S ? (kmask ? kmask[sv.row0 + key] : (uint8_t)1) : (uint8_t)0;
-        }
+        const int key = t * 64 + (tid & 63);
+        mok = key < S;
+        if (kmask) mraw = kmask[sv.row0 + min(max(key, 0), S - 1)];
     };
     auto lstore = [&](int stage) {
         char* st = smem + stage * kDqStage;
         lstore64_R(st, kr, tid);
         lstore64_R(st + 8192, vr, tid);
         if (tid < 64) {
+            const uint8_t mreg = mok ? mraw : (uint8_t)0;
             reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
             const unsigned long long valid = __ballot(mreg != 0);
             if (tid == 0) *reinterpret_cast<int*>(st + 16448) = (valid == ~0ull) ? 1 : 0;
@@ -474,20 +478,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
 
     TileRegs64 qr, gr;
-    float sreg = 0.f;
+    float sraw = 0.f;
+    bool sok = false;
+    const float* stat_src = (tid & 64) ? dlt_bh : lse_bh;
+    // Nothing in gload() consumes a loaded value (the first use is in lstore(), a whole tile of compute later): an arithmetic
+    // instruction on the fresh load made the compiler wait for the memory round trip right here, every tile.
     auto gload = [&](int t) {
         gload64(qr, qbase, ld, t * 64, S, tid);
         gload64(gr, dobase, ldo, t * 64, S, tid);
-        if (tid < 128) {
-            const int q = t * 64 + (tid & 63);
-            if (tid < 64) sreg = q < S ? -lse_bh[q] * kLog2e : kNegInf;  // -lse in log2 units; rows past S contribute p = 0
-            else sreg = q < S ? -dlt_bh[q] : 0.f;
-        }
+        const int q = t * 64 + (tid & 63);
+        sok = q < S;
+        sraw = stat_src[min(max(q, 0), S - 1)];  // raw lse (tid & 64 == 0) or delta; clamped address, judged by `sok`
     };
     auto lstore = [&](int stage) {
         char* st = smem + stage * kDkvStage;
         lstore64_R(st, qr, tid);
         lstore64_R(st + 8192, gr, tid);
+        // -lse in log2 units (rows past S contribute p = 0) and -delta
+        const float sreg = (tid & 64) ? (sok ? -sraw : 0.f) : (sok ? -sraw * kLog2e : kNegInf);
         if (tid < 128) reinterpret_cast<float*>(st + 16384)[tid] = sreg;
     };
 

@@ -195,7 +195,8 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
     kind = "<global>" if window < 0 else "<local>"
-    for stage, name, products in ((ATTN_BWD_DQ, "attn_bwd_dq_kernel", 1), (ATTN_BWD_DKV, "attn_bwd_dkv_kernel", 3)):
+    v = "3" if window < 0 else ""  # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip (names as rocprof shows them)
+    for stage, name, products in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel", 1), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel", 3)):
         call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh,
              window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, stream(), tag=name + kind,
              work=2.0 * products * B * nh * S * keys * 64)
@@ -219,7 +220,8 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
     kind = "<global,varlen>" if window < 0 else "<local,varlen>"
-    for stage, name in ((ATTN_BWD_DQ, "attn_bwd_dq_kernel"), (ATTN_BWD_DKV, "attn_bwd_dkv_kernel")):
+    v = "3" if window < 0 else ""
+    for stage, name in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel"), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel")):
         call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s,
              qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, stream(), tag=name + kind)
     return dqkv
