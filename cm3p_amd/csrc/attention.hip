@@ -603,8 +603,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 }  // namespace
 
+// attention_fwd.hip: the global-layer (window < 0) forward kernel
+int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, float scale,
+                                const int* cu_seqlens, int64_t total, hipStream_t s);
+
+static bool band_kernels_everywhere();
+
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                            float scale, VarLen vl, hipStream_t s) {
+    if (window < 0 && !band_kernels_everywhere()) return cm3p_launch_attn_fwd_global(qkv, out, lse, key_mask, B, S, nh, scale, vl.cu, vl.total, s);
     // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
     // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
@@ -617,9 +624,9 @@ int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* do
                                 const uint8_t* key_mask, int B, int S, int nh, float scale, const float* cos_tab, const float* sin_tab,
                                 int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, hipStream_t s);
 
-// Kernel experiments only: CM3P_ATTN_BWD_BAND_EVERYWHERE=1 routes global layers through the band kernels below as well.
+// Kernel experiments only: CM3P_ATTN_BAND_EVERYWHERE=1 routes global layers through the band kernels of this file as well.
 static bool band_kernels_everywhere() {
-    static const bool v = [] { const char* e = getenv("CM3P_ATTN_BWD_BAND_EVERYWHERE"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char* e = getenv("CM3P_ATTN_BAND_EVERYWHERE"); return e && e[0] == '1'; }();
     return v;
 }
 

@@ -383,28 +383,17 @@ constexpr int kSlots3 = 4;
 #ifndef CM3P_ABL
 #define CM3P_ABL 0  // timing-only ablation builds (tools/ubench/attn_bwd_ablate.sh): 1 no barrier, 2 no tile staging, 4 no fragment reloads, 8 no exponentials
 #endif
-#define CM3P_SB() __builtin_amdgcn_sched_barrier(0)
 #if CM3P_ABL & 16  // timing only: every score MFMA starts from the row constants (no accumulate chain)
 #define SC_ACC(d, a, b, c) mfma_vc(d, a, b, c)
 #else
 #define SC_ACC(d, a, b, c) mfma_va(d, a, b)
 #endif
 
-// D (VGPRs) = A (VGPRs) * B (AGPRs) + C (VGPRs); D never overlaps an input
-__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
-}
-// D += A * B (same registers)
-__device__ __forceinline__ void mfma_va(f32x16& d, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-}
 __device__ __forceinline__ void exp2_pair(f32x16& s, int i, float cm) {
     if constexpr ((CM3P_ABL & 8) != 0) return;
     s[i] = __builtin_amdgcn_exp2f(s[i] * cm);
     s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1] * cm);
 }
-__device__ __forceinline__ bf16x8 ld_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ bf16x8 ld_fragT(const char* lo, const char* hi) { return cat_bf16x4(lds_read_tr16(lo), lds_read_tr16(hi)); }
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
@@ -582,32 +571,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[3] = ld_frag(nS + 8192 + oR[3]);
         CM3P_SB();
         // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS
+#if CM3P_ABL & 32
+        const bf16x8 pf0 = Qf[0], ds0 = Gf[0], pf1 = Qf[1], ds1 = Gf[1];
+#define CM3P_VALU(x)
+#else
+#define CM3P_VALU(x) x
         const bf16x8 pf0 = acc_to_frag(Xs, 0);
+#endif
         dv[0][KBX] = mfma32(gT[0][0], pf0, dv[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Xdp[i] *= Xs[i];
+        CM3P_VALU(_Pragma("unroll") for (int i = 0; i < 4; ++i) Xdp[i] *= Xs[i];)
         CM3P_SB();
         dv[1][KBX] = mfma32(gT[0][1], pf0, dv[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 0);
-#pragma unroll
-        for (int i = 4; i < 8; ++i) Xdp[i] *= Xs[i];
-        const bf16x8 ds0 = acc_to_frag(Xdp, 0);
+        CM3P_VALU(_Pragma("unroll") for (int i = 4; i < 8; ++i) Xdp[i] *= Xs[i];)
+        CM3P_VALU(const bf16x8 ds0 = acc_to_frag(Xdp, 0);)
         CM3P_SB();
         dk[0][KBX] = mfma32(qT[0][0], ds0, dk[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 1);
-        const bf16x8 pf1 = acc_to_frag(Xs, 1);
+        CM3P_VALU(const bf16x8 pf1 = acc_to_frag(Xs, 1);)
         CM3P_SB();
         dk[1][KBX] = mfma32(qT[0][1], ds0, dk[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 1);
-#pragma unroll
-        for (int i = 8; i < 12; ++i) Xdp[i] *= Xs[i];
+        CM3P_VALU(_Pragma("unroll") for (int i = 8; i < 12; ++i) Xdp[i] *= Xs[i];)
         CM3P_SB();
         dv[0][KBX] = mfma32(gT[1][0], pf1, dv[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 0, 0);
-#pragma unroll
-        for (int i = 12; i < 16; ++i) Xdp[i] *= Xs[i];
-        const bf16x8 ds1 = acc_to_frag(Xdp, 1);
+        CM3P_VALU(_Pragma("unroll") for (int i = 12; i < 16; ++i) Xdp[i] *= Xs[i];)
+        CM3P_VALU(const bf16x8 ds1 = acc_to_frag(Xdp, 1);)
         CM3P_SB();
         dv[1][KBX] = mfma32(gT[1][1], pf1, dv[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 1, 0);
@@ -735,10 +726,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
 // -----------------------------------------------------------------------------------------------------------------------------
 constexpr int kDq3Stage = 2 * 8192;
 
-// D (VGPRs) = A (VGPRs) * B (AGPRs), from zero
-__device__ __forceinline__ void mfma_v0(f32x16& d, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-}
 __device__ __forceinline__ void exp2_fma_pair(f32x16& s, int i, float cm, float nl) {
     s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], cm, nl));
     s[i + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i + 1], cm, nl));

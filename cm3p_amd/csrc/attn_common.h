@@ -126,4 +126,28 @@ __device__ __forceinline__ void lstore64_R(char* tile, const TileRegs64& t, int 
     }
 }
 
+
+// ---- hand-scheduled kernels (attention_bwd.hip, attention_fwd.hip) --------------------------------------------------------------
+// With the 512-entry register budget of one wave per SIMD hipcc selects the AGPR form of every MFMA it generates, and the VALU
+// cannot read AGPRs.  Products whose results the VALU consumes are therefore issued as inline-asm MFMAs with VGPR destinations;
+// their stationary B operands live in AGPRs ("a").  hipcc pads no hazards for an asm statement: a result is first read one
+// pipeline step (hundreds of cycles) after it was issued, behind a sched_barrier, and an AGPR operand must never be
+// (re)materialised right in front of the MFMA (tests/test_kernel_isa.py checks the generated loops).
+#define CM3P_SB() __builtin_amdgcn_sched_barrier(0)
+
+// D (VGPRs) = A (VGPRs) * B (AGPRs) + C (VGPRs); D never overlaps an input
+__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+// D += A * B (same registers)
+__device__ __forceinline__ void mfma_va(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ bf16x8 ld_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 ld_fragT(const char* lo, const char* hi) { return cat_bf16x4(lds_read_tr16(lo), lds_read_tr16(hi)); }
+// D (VGPRs) = A (VGPRs) * B (AGPRs), from zero
+__device__ __forceinline__ void mfma_v0(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+
 }  // namespace
