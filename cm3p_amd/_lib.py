@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -31,14 +31,14 @@ SIGNATURES = {
     "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
     "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
-    "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _P],
+    "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],
     "cm3p_gemm_wgrad_splits": [_L, _L, _L],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
     "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
-    "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _P],
+    "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _I, _P],
     "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
     "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],
     "cm3p_gelu_fwd": [_P, _P, _L, _P],
@@ -69,8 +69,8 @@ SIGNATURES = {
     "cm3p_dot_f32": [_P, _P, _P, _L, _P],
     "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
     "cm3p_pointwise_loss": [_P, _P, _P, _P, _L, _I, _P],
-    "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P],
-    "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P],
+    "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _I, _P],
+    "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _I, _P],
     "cm3p_gather_rows_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_gemm_bf16_batched": [_P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _F, _F, _P],

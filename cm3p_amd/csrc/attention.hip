@@ -62,7 +62,10 @@ constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask 
 // QSUB = number of 32-query sub-blocks per wave.  With QSUB = 2 a wave carries two independent softmax chains: the
 // MFMAs of one sub-block overlap the VALU work of the other inside a single instruction stream (one wave cannot hide
 // its own MFMA -> VALU -> MFMA dependency), and every K / V fragment read from LDS feeds twice the work.
-template <int QSUB>
+// PRE: the q third already holds q * scale * log2(e) (cm3p_qkv_gemm_rope's q_scale): the MFMA delivers scores in exp2 units and the
+// reference point rides in as the initial accumulator.  !PRE: plain q; scale * log2(e) and the reference point are applied by one
+// fp32 v_fma per score - q is never re-rounded to bf16.
+template <int QSUB, bool PRE>
 __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                                         float* __restrict__ lse, const uint8_t* __restrict__ kmask,
                                                                         int Smax, int nh, int window, float scale, VarLen vl) {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
     constexpr float kDefer = 6.0f;
 
     int qrow[QSUB], lo[QSUB], hi[QSUB];
-    bf16x8 qf[QSUB][4];  // Q * (scale * log2 e): scores come out of the MFMA in exp2 units
+    bf16x8 qf[QSUB][4];
     f32x16 oacc[QSUB][2];
     // Softmax state per query (= per lane): mc_run is the reference point in log2 units that every stored p, l and O is
     // relative to; it is subtracted inside the MFMA (as the initial accumulator) and only moved when a tile maximum
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
         const int qc = qrow[u] < S ? qrow[u] : S - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            qf[u][s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 16 * s + 8 * hh), c);
+            qf[u][s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 16 * s + 8 * hh);
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[u][0][i] = oacc[u][1][i] = 0.f;
         mc_run[u] = 0.f;
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sacc[u][blk][i] = -mc_run[u];
-            // S^T = K (cQ)^T - reference: each K fragment is read from LDS once and used by every sub-block
+                    for (int i = 0; i < 16; ++i) sacc[u][blk][i] = PRE ? -mc_run[u] : 0.f;
+            // S^T = K Q^T (- reference): each K fragment is read from LDS once and used by every sub-block
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -172,6 +175,12 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
             const int all_valid = *reinterpret_cast<const int*>(st + 16448);
 #pragma unroll
             for (int u = 0; u < QSUB; ++u) {
+                if constexpr (!PRE) {
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sacc[u][blk][i] = __builtin_fmaf(sacc[u][blk][i], c, -mc_run[u]);
+                }
                 if (!tile_unmasked(all_valid, key0, q0 + 32 * u, window)) {
                     const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
                     mask_scores_keyrows(sacc[u][0], mb, 0, key0, lo[u], hi[u], hh);
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDqStage = 2 * 8192 + 64 + 16;  // K image, V image, mask bytes, all-valid flag
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
                                                              float* __restrict__ delta,
@@ -277,14 +287,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const int qrow_c = qrow < S ? qrow : S - 1;
     const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
     const float c = scale * kLog2e;
-    bf16x8 qf[4], dof[4];  // qf = Q * (scale * log2 e): K qf^T - lse*log2(e) is log2 of the probability
+    bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh), c);
+        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
         dof[s] = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
     }
     const int64_t stat = sv.stat0 + qrow_c;
-    const float lse2 = lse[stat] * kLog2e;  // +inf for rows with no visible key -> p = 0
+    // PRE: scores arrive in exp2 units, the accumulator starts at -lse * log2(e); !PRE: it starts at -lse / scale and the
+    // exponent is c * accumulator (fp32 multiply per score).  +inf lse (no visible key) -> p = 0 either way.
+    const float lse2 = PRE ? lse[stat] * kLog2e : lse[stat] / scale;
     // delta[q] = sum_d dO[q, d] O[q, d]: this lane holds half of its query's dO row already; the other half sits 32 lanes
     // away.  Written out for the dK/dV kernel, which runs after this one (no separate delta launch, one less pass over dO).
     float dlt = 0.f;
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[blk][i]);
+                    const float p = __builtin_amdgcn_exp2f(PRE ? sacc[blk][i] : sacc[blk][i] * c);
                     sacc[blk][i] = p * dp[blk][i];  // dS^T / scale (the scale is applied once, to dQ)
                 }
 #pragma unroll
@@ -425,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, -lse*log2e and -delta rows
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
@@ -452,10 +465,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const int krow = k0 + (lane & 31);
     const int krow_c = krow < S ? krow : S - 1;
     const float c = scale * kLog2e;
-    bf16x8 kf[4], vf[4];  // kf = K * (scale * log2 e)
+    bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh), c);
+        kf[s] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
         vf[s] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
     }
     const bool key_ok = krow < S && (kmask ? kmask[sv.row0 + krow] != 0 : true);
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
         lstore64_R(st, qr, tid);
         lstore64_R(st + 8192, gr, tid);
         // -lse in log2 units (rows past S contribute p = 0) and -delta
-        const float sreg = (tid & 64) ? (sok ? -sraw : 0.f) : (sok ? -sraw * kLog2e : kNegInf);
+        const float sreg = (tid & 64) ? (sok ? -sraw : 0.f) : (sok ? -sraw * (PRE ? kLog2e : 1.0f / scale) : kNegInf);
         if (tid < 128) reinterpret_cast<float*>(st + 16384)[tid] = sreg;
     };
 
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 if (plain) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[i]);
+                        const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
                         sacc[i] = p;
                         dp[i] = p * dp[i];  // dS / scale (applied once, to dK)
                     }
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                             const int i = 4 * g + r;
                             const int q = qb0 + 8 * g + 4 * hh + r;
                             const bool ok = key_ok & (q >= lo) & (q <= hi);
-                            const float p = ok ? __builtin_amdgcn_exp2f(sacc[i]) : 0.f;
+                            const float p = ok ? __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c) : 0.f;
                             sacc[i] = p;
                             dp[i] = p * dp[i];  // dS / scale (applied once, to dK)
                         }
@@ -592,9 +605,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = 32 * blk + 8 * g + 4 * hh;
+                // PRE: the products were taken with q * scale * log2(e), so dK = ln(2) * accumulator
+                const float ks = PRE ? 0.69314718055994531f : scale;
                 *reinterpret_cast<uint2*>(dkrow + d) =
-                    uint2{pack_bf16x2(dk[blk][4 * g] * scale, dk[blk][4 * g + 1] * scale),
-                          pack_bf16x2(dk[blk][4 * g + 2] * scale, dk[blk][4 * g + 3] * scale)};
+                    uint2{pack_bf16x2(dk[blk][4 * g] * ks, dk[blk][4 * g + 1] * ks), pack_bf16x2(dk[blk][4 * g + 2] * ks, dk[blk][4 * g + 3] * ks)};
                 *reinterpret_cast<uint2*>(dvrow + d) =
                     uint2{pack_bf16x2(dv[blk][4 * g], dv[blk][4 * g + 1]), pack_bf16x2(dv[blk][4 * g + 2], dv[blk][4 * g + 3])};
             }
@@ -603,26 +617,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 }  // namespace
 
-// attention_fwd.hip: the global-layer (window < 0) forward kernel
-int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, float scale,
-                                const int* cu_seqlens, int64_t total, hipStream_t s);
-
-static bool band_kernels_everywhere();
-
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
-                           float scale, VarLen vl, hipStream_t s) {
-    if (window < 0 && !band_kernels_everywhere()) return cm3p_launch_attn_fwd_global(qkv, out, lse, key_mask, B, S, nh, scale, vl.cu, vl.total, s);
+                           float scale, VarLen vl, int pre, hipStream_t s) {
     // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
     // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    attn_fwd_kernel<1><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
+    if (pre) attn_fwd_kernel<1, true><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
+    else attn_fwd_kernel<1, false><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
     return CM3P_OK;
 }
 
 // attention_bwd.hip: the global-layer (window < 0) backward kernels
 int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                                 const uint8_t* key_mask, int B, int S, int nh, float scale, const float* cos_tab, const float* sin_tab,
-                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, hipStream_t s);
+                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, int pre, hipStream_t s);
 
 // Kernel experiments only: CM3P_ATTN_BAND_EVERYWHERE=1 routes global layers through the band kernels of this file as well.
 static bool band_kernels_everywhere() {
@@ -633,29 +641,35 @@ static bool band_kernels_everywhere() {
 // stages: CM3P_ATTN_BWD_DQ (dq and delta) | CM3P_ATTN_BWD_DKV (dk, dv; reads the delta the dq stage wrote)
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                           const float* sin_tab, int64_t pos_batch_stride, VarLen vl, int stages, hipStream_t s) {
+                           const float* sin_tab, int64_t pos_batch_stride, VarLen vl, int stages, int pre, hipStream_t s) {
     if (window < 0 && !band_kernels_everywhere())
         return cm3p_launch_attn_bwd_global(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, scale, cos_tab, sin_tab, pos_batch_stride,
-                                           vl.cu, vl.total, stages, s);
+                                           vl.cu, vl.total, stages, pre, s);
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     if (stages & CM3P_ATTN_BWD_DQ) {
-        attn_bwd_dq_kernel<<<grid, 256, 2 * kDqStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv,
-                                                           key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+#define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
+        if (pre) attn_bwd_dq_kernel<true><<<grid, 256, 2 * kDqStage, s>>>(CM3P_DQ_ARGS);
+        else attn_bwd_dq_kernel<false><<<grid, 256, 2 * kDqStage, s>>>(CM3P_DQ_ARGS);
+#undef CM3P_DQ_ARGS
         if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
-    if (stages & CM3P_ATTN_BWD_DKV)
-        attn_bwd_dkv_kernel<<<grid, 256, 2 * kDkvStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                             key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+    if (stages & CM3P_ATTN_BWD_DKV) {
+#define CM3P_DKV_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
+        if (pre) attn_bwd_dkv_kernel<true><<<grid, 256, 2 * kDkvStage, s>>>(CM3P_DKV_ARGS);
+        else attn_bwd_dkv_kernel<false><<<grid, 256, 2 * kDkvStage, s>>>(CM3P_DKV_ARGS);
+#undef CM3P_DKV_ARGS
+    }
     return CM3P_OK;
 }
 
 extern "C" {
 
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
-                  float scale, void* stream) {
+                  float scale, int q_prescaled, void* stream) {
     CM3P_REQUIRE(qkv && out && lse && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
-    const int rc = launch_attn_fwd(qkv, out, lse, key_mask, B, S, nh, window, scale, VarLen{nullptr, 0}, static_cast<hipStream_t>(stream));
+    const int rc = launch_attn_fwd(qkv, out, lse, key_mask, B, S, nh, window, scale, VarLen{nullptr, 0}, q_prescaled != 0,
+                                   static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
@@ -663,24 +677,24 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
 
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                  const float* sin_tab, int64_t pos_batch_stride, int stages, void* stream) {
+                  const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
     CM3P_REQUIRE(stages >= 1 && stages <= 3);
     CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, window, scale, cos_tab, sin_tab,
-                                   pos_batch_stride, VarLen{nullptr, 0}, stages, static_cast<hipStream_t>(stream));
+                                   pos_batch_stride, VarLen{nullptr, 0}, stages, q_prescaled != 0, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
 
 int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_seqlens, int B, int max_seqlen, int64_t total,
-                         int nh, int window, float scale, void* stream) {
+                         int nh, int window, float scale, int q_prescaled, void* stream) {
     CM3P_REQUIRE(qkv && out && lse && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out));
-    const int rc = launch_attn_fwd(qkv, out, lse, nullptr, B, max_seqlen, nh, window, scale, VarLen{cu_seqlens, total},
+    const int rc = launch_attn_fwd(qkv, out, lse, nullptr, B, max_seqlen, nh, window, scale, VarLen{cu_seqlens, total}, q_prescaled != 0,
                                    static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
@@ -689,13 +703,13 @@ int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_s
 
 int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                          const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
-                         const float* cos_tab, const float* sin_tab, int stages, void* stream) {
+                         const float* cos_tab, const float* sin_tab, int stages, int q_prescaled, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
     CM3P_REQUIRE(stages >= 1 && stages <= 3);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, nullptr, B, max_seqlen, nh, window, scale, cos_tab, sin_tab, 0,
-                                   VarLen{cu_seqlens, total}, stages, static_cast<hipStream_t>(stream));
+                                   VarLen{cu_seqlens, total}, stages, q_prescaled != 0, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;

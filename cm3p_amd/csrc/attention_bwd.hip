@@ -5,23 +5,26 @@
 // mask of TF:masking_utils.py:168-179; the inverse of apply_rotary_pos_emb (TF:models/modernbert/modeling_modernbert.py:188-219)
 // is applied to dq / dk in the epilogues.
 //
-// Structure (both kernels): 8 waves per workgroup, two per SIMD, each wave owning 32 rows of the stationary operand (256 per
-// workgroup) and <= 256 registers, so every MFMA accumulator is an architectural VGPR the VALU reads directly (with the 512-entry
-// budget of one wave per SIMD hipcc selects the AGPR form of every MFMA and pays a v_accvgpr_read per score, measured in ISA:
-// +160 VALU instructions per 64-row tile).  64-row tiles of the streamed operands are staged global -> registers -> LDS one
-// tile ahead into a three-slot ring with a single workgroup barrier per tile; loads are branch-free (clamped rows).  Inside a
-// wave's instruction stream the loop is software pipelined over 32 x 32 score blocks: the score MFMAs of block n+1 are issued
-// next to the exponentials / products / bf16 packing of block n, whose gradient MFMAs follow - on this chip the matrix pipe
-// and the VALU of a SIMD overlap inside one wave's stream, so the overlap is written into it.
+// Structure (both kernels, details at each): ONE wave per SIMD with the whole 512-entry register file, 64 rows of the stationary
+// operand per wave (256 per 4-wave workgroup), 64-row tiles of the streamed operands staged global -> registers -> LDS into a
+// four-slot ring (two staging register sets: a tile's loads fly for two tile periods; one workgroup barrier per tile; no load
+// is consumed before its LDS store; loads are branch-free with clamped rows), and ONE hand-placed instruction stream per wave
+// (sched_barrier between chunks) that software-pipelines the tile's four 32 x 32 score blocks: score MFMAs of block n+1 next to
+// the exponentials of block n, then block n's gradient MFMAs next to its products / bf16 packs.  Score MFMAs are inline asm with
+// VGPR results (the VALU reads them) and AGPR-resident stationary operands; gradient MFMAs are compiler MFMAs with AGPR
+// accumulators.  LDS fragments are register-resident per 32-row block and reloaded a full step before their next use.
 //
-//   dkv  key on the lane: S = Q K^T and dP = dO V^T with -lse and -delta preloaded as the initial accumulators;
-//        dV^T += dO^T P and dK^T += Q^T dS take the score accumulators directly as B operands; dK^T, dV^T of the wave's 32 keys
-//        stay in 64 accumulator registers for the whole sweep over the queries.  Nothing is masked in the loop (see below).
-//   dq   query on the lane: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (K^T by transposed reads of
-//        the same LDS image); also computes delta = rowsum(dO o O) for its rows and publishes it for the dkv kernel.
+//   dkv  key on the lane: S = Q K^T and dP = dO V^T with the score offset (-lse) and -delta preloaded as initial accumulators;
+//        dV^T += dO^T P and dK^T += Q^T dS take the score accumulators directly as B operands.  Nothing is masked in the loop: a
+//        padded key only pollutes its own column of dK^T / dV^T, which the epilogue writes as zeros.
+//   dq   query on the lane: S^T = K Q^T, dP^T = V dO^T - delta, dS^T = P^T o dP^T, dQ^T += K^T dS^T (K^T by transposed reads of
+//        the same LDS image); also computes delta = rowsum(dO o O) for its rows and publishes it for the dkv kernel.  Invisible
+//        keys are staged with a zero K row, so nothing is masked in the loop.
 //
-// Scores are exponentiated as exp2(c * (q.k) - lse * log2 e) with c = scale * log2 e applied in fp32 on the accumulator
-// (one v_mul per score) - the operands are NOT pre-scaled and re-rounded to bf16.
+// Softmax scale: q_prescaled (cm3p_hip.h) - either q already carries scale * log2(e) (folded in before q's single bf16 rounding
+// by the Wqkv GEMM's epilogue) or the kernels multiply the fp32 score accumulators; q is never re-rounded to bf16.
+// Measured (C2 global layer, B 32 x 12 heads x 4096^2): dkv 3.96 -> 2.92 ms, dq 2.84 -> 2.48 ms against the 32-row-per-wave,
+// two-waves-per-SIMD kernels they replace (attention.hip, which still serves the sliding-window layers).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -30,334 +33,9 @@
 
 namespace {
 
-constexpr int kBwdStage = 2 * 8192 + 512;  // two 64 x 64 bf16 images + 128 floats (dkv: -lse / scale and -delta of the 64 rows)
-constexpr int kBwdStages = 3;
-constexpr int kBwdThreads = 512;
+constexpr int kBwdStage = 2 * 8192 + 512;  // two 64 x 64 bf16 images + 128 floats (dkv: the score offsets and -delta of the 64 rows)
 
 __device__ __forceinline__ bf16x8 gload_frag(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-
-// one 16-byte chunk per thread of rows r0 .. r0+63 of a [*, 64] bf16 matrix (512 threads), row index clamped into
-// [0, limit-1]: no branch, no out-of-range address; what the duplicated rows hold is made irrelevant by the caller (a -inf score
-// offset, or a zeroed row)
-__device__ __forceinline__ uint4 gload64x512(const uint16_t* base, int64_t ld, int r0, int limit, int tid) {
-    const int r = min(r0 + (tid >> 3), limit - 1);
-    return *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + (tid & 7) * 8);
-}
-__device__ __forceinline__ void lstore64x512(char* tile, uint4 v, int tid) { *reinterpret_cast<uint4*>(tile + off_R(tid >> 3, tid & 7)) = v; }
-
-// one 32 x 32 score block in place: s -> p = exp2(cm * s), dp -> p * dp   (cm = scale * log2 e, applied in fp32)
-__device__ __forceinline__ void softmax_grad_block(f32x16& s, f32x16& dp, float cm) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(s[i] * cm);
-        s[i] = p;
-        dp[i] = p * dp[i];
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------------------------------
-// dK, dV.  Workgroup = 256 keys of one (batch, head); wave w owns keys K0 + 32 w .. + 31 (key = MFMA column = lane & 31).
-// LDS slot: Q image (64 rows), dO image, -lse / scale and -delta of the 64 rows.
-// Whatever a padded key computes stays in its own column of dK^T / dV^T: nothing is masked in the loop, the epilogue writes
-// zeros for such keys.  Query rows past the end of the sequence are clamped re-reads whose score offset is -inf (p = 0).
-// -----------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBwdThreads, 2) void attn_bwd_dkv2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                       uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                                       int Smax, int nh, float scale, const float* __restrict__ rope_cos,
-                                                                       const float* __restrict__ rope_sin, int64_t pos_batch_stride,
-                                                                       VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
-    int kblk, head, b;
-    decode_block((Smax + 255) / 256, nh, kblk, head, b);
-    const int K0 = kblk * 256;
-    const SeqView sv(vl, b, head, Smax, nh);
-    const int S = sv.S;
-    if (K0 >= S) return;
-    const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
-    const uint16_t* kbase = qbase + nh * 64;
-    const uint16_t* vbase = qbase + 2 * nh * 64;
-    const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
-    const float* lse_bh = lse + sv.stat0;
-    const float* dlt_bh = delta + sv.stat0;
-    const float cm = scale * kLog2e;
-    const float lse_mul = -1.0f / scale;  // accumulators start at -lse / scale: cm * (q.k - lse / scale) = log2 p
-
-    const int krow = K0 + wid * 32 + (lane & 31);
-    bf16x8 kf[4], vf[4];
-    {
-        const int krow_c = min(krow, S - 1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kf[s] = gload_frag(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
-            vf[s] = gload_frag(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
-        }
-    }
-    f32x16 dk[2], dv[2];  // [d block]
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
-
-    const int n_tiles = (S + 63) / 64;
-    uint4 qr, gr;
-    float sreg;
-    auto gload = [&](int t) {  // branch-free; tiles past the end reload the last rows and are never used
-        qr = gload64x512(qbase, ld, t * 64, S, tid);
-        gr = gload64x512(dobase, ldo, t * 64, S, tid);
-        const int q = t * 64 + (tid & 63), qc = min(q, S - 1);
-        const float a = lse_bh[qc] * lse_mul, d = -dlt_bh[qc];
-        // rows past S (and rows whose lse is +inf: no visible key) start at -inf and give p = 0
-        sreg = (tid & 64) ? (q < S ? d : 0.f) : (q < S ? a : kNegInf);
-    };
-    auto lstore = [&](int slot) {
-        char* st = smem + slot * kBwdStage;
-        lstore64x512(st, qr, tid);
-        lstore64x512(st + 8192, gr, tid);
-        reinterpret_cast<float*>(st + 16384)[tid & 127] = sreg;  // (threads 128..511 repeat the same values)
-    };
-    // one 32-query x 32-key block: s = Q K^T - lse / scale, dp = dO V^T - delta   (rows = queries, lane = key)
-    auto scores = [&](const char* st, int qb, f32x16& s, f32x16& dp) {
-        const float* nlse = reinterpret_cast<const float*>(st + 16384) + 32 * qb + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 8 * g);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(nlse + 64 + 8 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[4 * g + r] = a[r];
-                dp[4 * g + r] = d[r];
-            }
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            s = mfma32(frag_R(st, 32 * qb, s4, lane), kf[s4], s);
-            dp = mfma32(frag_R(st + 8192, 32 * qb, s4, lane), vf[s4], dp);
-        }
-    };
-    // dV^T += dO^T P, dK^T += Q^T dS for that block
-    auto grads = [&](const char* st, int qb, const f32x16& s, const f32x16& dp) {
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const bf16x8 pf = acc_to_frag(s, sp), dsf = acc_to_frag(dp, sp);
-            const int r0 = 32 * qb + 16 * sp;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                dv[db] = mfma32(frag_T(st + 8192, r0, db, lane), pf, dv[db]);
-                dk[db] = mfma32(frag_T(st, r0, db, lane), dsf, dk[db]);
-            }
-        }
-    };
-
-    // prologue: tile 0 in slot 0, tile 1 in flight, scores of the first block
-    gload(0);
-    lstore(0);
-    gload(1);
-    __syncthreads();
-    f32x16 sA, dpA, sB, dpB;
-    scores(smem, 0, sA, dpA);
-
-    int slot = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        const int nslot = slot == kBwdStages - 1 ? 0 : slot + 1;
-        const char* st = smem + slot * kBwdStage;
-        const char* nst = smem + nslot * kBwdStage;
-        // tile t+1 (in registers since the previous iteration) goes to its slot, whose last readers finished tile t-2 before the
-        // previous barrier; then the loads of tile t+2 are issued.  One barrier per tile.
-        lstore(nslot);
-        __syncthreads();
-        gload(t + 2);
-        // software pipeline over the 32 x 32 blocks: the score MFMAs of block n+1 are independent of the exponentials /
-        // products / packing of block n, whose gradient MFMAs follow
-        scores(st, 1, sB, dpB);
-        softmax_grad_block(sA, dpA, cm);
-        grads(st, 0, sA, dpA);
-        scores(nst, 0, sA, dpA);  // first block of tile t+1 (past the last tile: computed on stale rows, never used)
-        softmax_grad_block(sB, dpB, cm);
-        grads(st, 1, sB, dpB);
-        slot = nslot;
-    }
-
-    // ---- epilogue: dK = scale * dK^T acc (inverse rotary applied), dV; keys under the padding mask get zeros
-    if (krow < S) {
-        const bool ok = kmask ? kmask[sv.row0 + krow] != 0 : true;
-        const float ks = ok ? scale : 0.f, vs = ok ? 1.f : 0.f;
-        uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
-        uint16_t* dvrow = dkrow + nh * 64;
-        if (!ok) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;  // (a masked column may hold inf / NaN)
-        }
-        if (rope_cos) {
-            const int64_t prow = sv.pos0(b, pos_batch_stride) + krow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 lo4 = {dk[0][4 * g], dk[0][4 * g + 1], dk[0][4 * g + 2], dk[0][4 * g + 3]};
-                f32x4 hi4 = {dk[1][4 * g], dk[1][4 * g + 1], dk[1][4 * g + 2], dk[1][4 * g + 3]};
-                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dk[0][4 * g + r] = lo4[r];
-                    dk[1][4 * g + r] = hi4[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = 32 * db + 8 * g + 4 * hh;
-                *reinterpret_cast<uint2*>(dkrow + d) = uint2{pack_bf16x2(dk[db][4 * g] * ks, dk[db][4 * g + 1] * ks),
-                                                             pack_bf16x2(dk[db][4 * g + 2] * ks, dk[db][4 * g + 3] * ks)};
-                *reinterpret_cast<uint2*>(dvrow + d) = uint2{pack_bf16x2(dv[db][4 * g] * vs, dv[db][4 * g + 1] * vs),
-                                                             pack_bf16x2(dv[db][4 * g + 2] * vs, dv[db][4 * g + 3] * vs)};
-            }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------------------------------
-// dQ and delta.  Workgroup = 256 queries of one (batch, head); wave w owns queries Q0 + 32 w .. + 31 (query = MFMA column).
-// LDS slot: K image (row and transposed reads), V image.
-// Keys under the padding mask (and rows past the end of the sequence) are staged with a ZERO K row: their scores and dS are
-// then finite garbage that multiplies a zero row of K^T in the dQ product - nothing is masked in the loop.
-// -----------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBwdThreads, 2) void attn_bwd_dq2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                                      const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
-                                                                      float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-                                                                      const uint8_t* __restrict__ kmask, int Smax, int nh, float scale,
-                                                                      const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                                      int64_t pos_batch_stride, VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
-    int qblk, head, b;
-    decode_block((Smax + 255) / 256, nh, qblk, head, b);
-    const int Q0 = qblk * 256;
-    const SeqView sv(vl, b, head, Smax, nh);
-    const int S = sv.S;
-    if (Q0 >= S) return;
-    const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
-    const uint16_t* kbase = qbase + nh * 64;
-    const uint16_t* vbase = qbase + 2 * nh * 64;
-    const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
-    const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
-    const uint8_t* km = kmask ? kmask + sv.row0 : nullptr;
-    const float cm = scale * kLog2e;
-
-    const int qrow = Q0 + wid * 32 + (lane & 31);
-    const int qrow_c = min(qrow, S - 1);
-    bf16x8 qf[4], dof[4];
-    f32x16 lse_init, dlt_init;
-    {
-        float dlt = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            qf[s] = gload_frag(qbase + (int64_t)qrow_c * ld + 16 * s + 8 * hh);
-            dof[s] = gload_frag(dobase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
-            const bf16x8 of = gload_frag(obase + (int64_t)qrow_c * ldo + 16 * s + 8 * hh);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dlt += (float)of[j] * (float)dof[s][j];
-        }
-        // delta[q] = sum_d dO[q, d] O[q, d]: the other half of the row sits 32 lanes away.  Published for the dkv kernel.
-        dlt += __shfl_xor(dlt, 32, 64);
-        const int64_t stat = sv.stat0 + qrow_c;
-        if (hh == 0 && qrow < S) delta[stat] = dlt;
-        const float li = -lse[stat] / scale;  // -inf for rows with no visible key -> p = 0
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            lse_init[i] = li;
-            dlt_init[i] = -dlt;
-        }
-    }
-    f32x16 dq[2];  // [d block]
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
-
-    const int n_tiles = (S + 63) / 64;
-    uint4 kr, vr;
-    auto gload = [&](int t) {
-        kr = gload64x512(kbase, ld, t * 64, S, tid);
-        vr = gload64x512(vbase, ld, t * 64, S, tid);
-        const int key = t * 64 + (tid >> 3);  // zero the K rows of keys that no query may see
-        const bool ok = key < S && (km ? km[min(key, S - 1)] != 0 : true);
-        if (!ok) kr = uint4{0u, 0u, 0u, 0u};
-    };
-    auto lstore = [&](int slot) {
-        char* st = smem + slot * kBwdStage;
-        lstore64x512(st, kr, tid);
-        lstore64x512(st + 8192, vr, tid);
-    };
-    // one 32-key x 32-query block: s = K Q^T - lse / scale, dp = V dO^T - delta   (rows = keys, lane = query)
-    auto scores = [&](const char* st, int kb, f32x16& s, f32x16& dp) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            s = mfma32(frag_R(st, 32 * kb, s4, lane), qf[s4], s4 == 0 ? lse_init : s);
-            dp = mfma32(frag_R(st + 8192, 32 * kb, s4, lane), dof[s4], s4 == 0 ? dlt_init : dp);
-        }
-    };
-    // dQ^T += K^T dS^T for that block (K^T from the image the row reads use)
-    auto grads = [&](const char* st, int kb, const f32x16& dp) {
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const bf16x8 dsf = acc_to_frag(dp, sp);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) dq[db] = mfma32(frag_T(st, 32 * kb + 16 * sp, db, lane), dsf, dq[db]);
-        }
-    };
-
-    gload(0);
-    lstore(0);
-    gload(1);
-    __syncthreads();
-    f32x16 sA, dpA, sB, dpB;
-    scores(smem, 0, sA, dpA);
-
-    int slot = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        const int nslot = slot == kBwdStages - 1 ? 0 : slot + 1;
-        const char* st = smem + slot * kBwdStage;
-        const char* nst = smem + nslot * kBwdStage;
-        lstore(nslot);
-        __syncthreads();
-        gload(t + 2);
-        scores(st, 1, sB, dpB);
-        softmax_grad_block(sA, dpA, cm);  // dp = dS^T / scale (the scale is applied once, to dQ)
-        grads(st, 0, dpA);
-        scores(nst, 0, sA, dpA);
-        softmax_grad_block(sB, dpB, cm);
-        grads(st, 1, dpB);
-        slot = nslot;
-    }
-
-    if (qrow < S) {
-        uint16_t* drow = dqkv + (sv.row0 + qrow) * ld + head * 64;
-        if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
-            const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 lo4 = {dq[0][4 * g], dq[0][4 * g + 1], dq[0][4 * g + 2], dq[0][4 * g + 3]};
-                f32x4 hi4 = {dq[1][4 * g], dq[1][4 * g + 1], dq[1][4 * g + 2], dq[1][4 * g + 3]};
-                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dq[0][4 * g + r] = lo4[r];
-                    dq[1][4 * g + r] = hi4[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = 32 * db + 8 * g + 4 * hh;
-                *reinterpret_cast<uint2*>(drow + d) = uint2{pack_bf16x2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale),
-                                                            pack_bf16x2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale)};
-            }
-    }
-}
-
 
 // -----------------------------------------------------------------------------------------------------------------------------
 // dK, dV, hand-scheduled: ONE wave per SIMD with the whole 512-entry register file, wave w owns keys K0 + 64 w .. + 63 (two
@@ -389,12 +67,15 @@ constexpr int kSlots3 = 4;
 #define SC_ACC(d, a, b, c) mfma_va(d, a, b)
 #endif
 
+// PRE: scores arrive in exp2 units (q carries scale * log2 e); !PRE: one fp32 multiply per score
+template <bool PRE>
 __device__ __forceinline__ void exp2_pair(f32x16& s, int i, float cm) {
     if constexpr ((CM3P_ABL & 8) != 0) return;
-    s[i] = __builtin_amdgcn_exp2f(s[i] * cm);
-    s[i + 1] = __builtin_amdgcn_exp2f(s[i + 1] * cm);
+    s[i] = __builtin_amdgcn_exp2f(PRE ? s[i] : s[i] * cm);
+    s[i + 1] = __builtin_amdgcn_exp2f(PRE ? s[i + 1] : s[i + 1] * cm);
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
@@ -418,7 +99,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
     const float* lse_bh = lse + sv.stat0;
     const float* dlt_bh = delta + sv.stat0;
     const float cm = scale * kLog2e;
-    const float lse_mul = -1.0f / scale;  // accumulators start at -lse / scale: cm * (q.k - lse / scale) = log2 p
+    // the score accumulators start at -lse * log2(e) (PRE: q carries scale * log2 e, the MFMA delivers log2 p) or at -lse / scale
+    // (!PRE: cm * (q.k - lse / scale) = log2 p)
+    const float lse_mul = PRE ? -kLog2e : -1.0f / scale;
 
     bf16x8 kf[2][4], vf[2][4];  // B operands of the asm MFMAs ("a" constraint: they live in AGPRs)
 #pragma unroll
@@ -527,10 +210,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         constexpr int KBX = decltype(kbx_c)::value, KBY = decltype(kby_c)::value;
         CM3P_SB();
         mfma_vc(Ys, Qf[0], kf[KBY][0], isv);
-        exp2_pair(Xs, 0, cm);
+        exp2_pair<PRE>(Xs, 0, cm);
         CM3P_SB();
         mfma_vc(Ydp, Gf[0], vf[KBY][0], idv);
-        exp2_pair(Xs, 2, cm);
+        exp2_pair<PRE>(Xs, 2, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
             Qf[0] = ld_frag(nS + oR[0]);
             Gf[0] = ld_frag(nS + 8192 + oR[0]);
@@ -538,36 +221,36 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         }
         CM3P_SB();
         SC_ACC(Ys, Qf[1], kf[KBY][1], isv);
-        exp2_pair(Xs, 4, cm);
+        exp2_pair<PRE>(Xs, 4, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
             load_init(nSi, isv, 0, 1);
             Qf[1] = ld_frag(nS + oR[1]);
         }
         CM3P_SB();
         SC_ACC(Ydp, Gf[1], vf[KBY][1], idv);
-        exp2_pair(Xs, 6, cm);
+        exp2_pair<PRE>(Xs, 6, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
             Gf[1] = ld_frag(nS + 8192 + oR[1]);
             load_init(nSi, idv, 1, 0);
         }
         CM3P_SB();
         SC_ACC(Ys, Qf[2], kf[KBY][2], isv);
-        exp2_pair(Xs, 8, cm);
+        exp2_pair<PRE>(Xs, 8, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) {
             Qf[2] = ld_frag(nS + oR[2]);
             load_init(nSi, idv, 1, 1);
         }
         CM3P_SB();
         SC_ACC(Ydp, Gf[2], vf[KBY][2], idv);
-        exp2_pair(Xs, 10, cm);
+        exp2_pair<PRE>(Xs, 10, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[2] = ld_frag(nS + 8192 + oR[2]);
         CM3P_SB();
         SC_ACC(Ys, Qf[3], kf[KBY][3], isv);
-        exp2_pair(Xs, 12, cm);
+        exp2_pair<PRE>(Xs, 12, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Qf[3] = ld_frag(nS + oR[3]);
         CM3P_SB();
         SC_ACC(Ydp, Gf[3], vf[KBY][3], idv);
-        exp2_pair(Xs, 14, cm);
+        exp2_pair<PRE>(Xs, 14, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[3] = ld_frag(nS + 8192 + oR[3]);
         CM3P_SB();
         // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS
@@ -675,7 +358,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         const int krow = k0 + 32 * kb + (lane & 31);
         if (krow < S) {
             const bool ok = kmask ? kmask[sv.row0 + krow] != 0 : true;
-            const float ks = ok ? scale : 0.f, vs = ok ? 1.f : 0.f;
+            // PRE: the products were taken with q * scale * log2(e), so dK = ln(2) * accumulator
+            const float ks = ok ? (PRE ? 0.69314718055994531f : scale) : 0.f, vs = ok ? 1.f : 0.f;
             uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
             uint16_t* dvrow = dkrow + nh * 64;
             if (!ok) {
@@ -736,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(const uint16_t* __
                                                               float* __restrict__ delta, uint16_t* __restrict__ dqkv,
                                                               const uint8_t* __restrict__ kmask, int Smax, int nh, float scale,
                                                               const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                              int64_t pos_batch_stride, VarLen vl) {
+                                                              int64_t pos_batch_stride, VarLen vl, int pre) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     int qblk, head, b;
@@ -753,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(const uint16_t* __
     const int64_t ldo = (int64_t)nh * 64;
     const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
     const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
-    const float cm = scale * kLog2e;
+    const float cm = pre ? 1.0f : scale * kLog2e;  // (q carries scale * log2 e when pre: the v_fma then only adds -lse * log2 e)
 
     bf16x8 qf[2][4], dof[2][4];  // B operands of the asm MFMAs ("a" constraint: they live in AGPRs)
     f32x16 dlt_init[2];
@@ -1002,29 +686,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq3_kernel(const uint16_t* __
 // Launcher used by attention.hip's cm3p_attn_bwd / cm3p_attn_bwd_varlen for window < 0.
 int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                                 const uint8_t* key_mask, int B, int S, int nh, float scale, const float* cos_tab, const float* sin_tab,
-                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, hipStream_t s) {
+                                int64_t pos_batch_stride, const int* cu_seqlens, int64_t total, int stages, int pre, hipStream_t s) {
     const VarLen vl{cu_seqlens, total};
     const dim3 grid(((S + 255) / 256) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    const size_t lds = kBwdStages * kBwdStage;
     if (stages & CM3P_ATTN_BWD_DQ) {
-        static const bool v2 = [] { const char* e = getenv("CM3P_ATTN_BWD_DQ"); return e && e[0] == '2'; }();  // kernel experiments only
-        if (v2)
-            attn_bwd_dq2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta,
-                                                               (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
-        else
-            attn_bwd_dq3_kernel<<<grid, 256, kSlots3 * kDq3Stage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta,
-                                                                       (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab,
-                                                                       pos_batch_stride, vl);
+        attn_bwd_dq3_kernel<<<grid, 256, kSlots3 * kDq3Stage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta,
+                                                                   (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl, pre);
         if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
     if (stages & CM3P_ATTN_BWD_DKV) {
-        static const bool v2 = [] { const char* e = getenv("CM3P_ATTN_BWD_DKV"); return e && e[0] == '2'; }();  // kernel experiments only
-        if (v2)
-            attn_bwd_dkv2_kernel<<<grid, kBwdThreads, lds, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S,
-                                                                nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
-        else
-            attn_bwd_dkv3_kernel<<<grid, 256, kSlots3 * kBwdStage, s>>>((const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                                                                        key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+#define CM3P_DKV3_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl
+        if (pre) attn_bwd_dkv3_kernel<true><<<grid, 256, kSlots3 * kBwdStage, s>>>(CM3P_DKV3_ARGS);
+        else attn_bwd_dkv3_kernel<false><<<grid, 256, kSlots3 * kBwdStage, s>>>(CM3P_DKV3_ARGS);
+#undef CM3P_DKV3_ARGS
     }
     return CM3P_OK;
 }

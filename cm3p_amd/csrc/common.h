@@ -57,6 +57,10 @@ struct RopeArgs {
     int S;
     int per_batch;
     int ncols;
+    // the first q_cols columns (the q third) are additionally multiplied by q_scale, in fp32, before the single bf16 rounding of
+    // the rotated value: the attention kernels then get softmax-ready scores (scale * log2 e folded in) without a second rounding
+    int q_cols = 0;
+    float q_scale = 1.f;
 };
 
 // a = head dims [d, d+3], b = head dims [d+32, d+35] of one token (d < 32): rotate_half convention

@@ -176,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* A, co
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     rope_rotate4<false>(acc[i][j], acc[i][j + 2], rope.cos + prow * 32, rope.sin + prow * 32, j * 16 + 4 * (lane >> 4));
+                if (n0 + wn * 64 < rope.q_cols) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] *= rope.q_scale;
+                }
             }
         }
 #pragma unroll
@@ -283,13 +287,14 @@ int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, int64_t N, int64_t K, const float* cos_tab,
-                       const float* sin_tab, int S, int per_batch, int rope_cols, void* stream) {
+                       const float* sin_tab, int S, int per_batch, int rope_cols, float q_scale, void* stream) {
     CM3P_REQUIRE(x && Wqkv && qkv && cos_tab && sin_tab && M > 0 && N > 0 && K > 0 && S > 0);
     CM3P_REQUIRE(cm3p_aligned16(x) && cm3p_aligned16(Wqkv) && cm3p_aligned16(qkv) && cm3p_aligned16(cos_tab) && cm3p_aligned16(sin_tab));
     CM3P_REQUIRE(K % 8 == 0 && N % 64 == 0 && rope_cols % 64 == 0 && rope_cols >= 0 && rope_cols <= N);
     CM3P_REQUIRE(per_batch || M % S == 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const RopeArgs rope{cos_tab, sin_tab, S, per_batch, rope_cols};
+    CM3P_REQUIRE(q_scale > 0.f && rope_cols % 2 == 0);
+    const RopeArgs rope{cos_tab, sin_tab, S, per_batch, rope_cols, rope_cols / 2, q_scale};
     // (the 256 x 256 kernel decides per tile whether its columns are rotated: the rotated range must end on a tile boundary)
     const bool big = (K % 64 == 0) && (rope_cols % 256 == 0) && M < (int64_t(1) << 31) && tiles_of(M, N, 256) >= 200;
     int rc;

@@ -300,11 +300,12 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
                                 const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                                 const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
                                 uint32_t oa[4], ob[4];
+                                const float qs = n < rope.q_cols ? rope.q_scale : 1.f;  // q columns: softmax scale folded in before the rounding
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
                                     const float a0 = bf16lo(wa[t]), a1 = bf16hi(wa[t]), b0 = bf16lo(wb[t]), b1 = bf16hi(wb[t]);
-                                    oa[t] = pack_bf16x2(a0 * cs[2 * t] - b0 * sn[2 * t], a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]);
-                                    ob[t] = pack_bf16x2(b0 * cs[2 * t] + a0 * sn[2 * t], b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]);
+                                    oa[t] = pack_bf16x2(qs * (a0 * cs[2 * t] - b0 * sn[2 * t]), qs * (a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]));
+                                    ob[t] = pack_bf16x2(qs * (b0 * cs[2 * t] + a0 * sn[2 * t]), qs * (b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]));
                                 }
                                 *reinterpret_cast<uint4*>(C + m * ldc + n) = uint4{oa[0], oa[1], oa[2], oa[3]};
                                 *reinterpret_cast<uint4*>(C + m * ldc + n + 32) = uint4{ob[0], ob[1], ob[2], ob[3]};

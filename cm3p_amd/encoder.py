@@ -130,11 +130,13 @@ def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
         xn, mean_a, rstd_a = K.cast_bf16(x), None, None
     else:
         _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, want_stats)
-    qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos)  # projection + RoPE in one kernel
+    # projection + RoPE in one kernel; the q third also takes the softmax's scale * log2(e) before its one bf16 rounding, so the
+    # attention kernels exponentiate the MFMA's scores as they come (prescaled=True everywhere below)
+    qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos, q_scale=K.SOFTMAX_Q_SCALE)
     if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
-        o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale)
+        o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, prescaled=True)
     else:
-        o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale)
+        o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True)
     x_mid = K.linear_fwd(o, Wo_b, resid=x)
     _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
     h = K.linear_fwd(xn2, Wi_b)
@@ -199,9 +201,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         dWo = K.linear_wgrad(gx16, o) if n_o else None
         # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
         if geo.cu is not None:
-            dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i])
+            dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i], prescaled=True)
         else:
-            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos)
+            dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos,
+                              prescaled=True)
         del do, o, qkv
         dWqkv = K.linear_wgrad(dqkv, xn) if n_qkv else None
         if i == 0:

@@ -119,12 +119,16 @@ def linear_fwd(x: Tensor, w: Tensor, resid: Optional[Tensor] = None) -> Tensor:
     return gemm(x, w, T, N, K, True, True, EPI_F32_RESID if resid is not None else EPI_BF16, resid)
 
 
-def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_batch: bool) -> Tensor:
-    """Fused Wqkv projection + RoPE on the q and k thirds: x [T,H] bf16, w [3H,H] bf16 -> qkv [T,3H] bf16 (rotated)."""
+SOFTMAX_Q_SCALE = 64 ** -0.5 * 1.4426950408889634  # scale * log2(e) for head_dim 64: what q_prescaled attention expects in q
+
+
+def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_batch: bool, q_scale: float = 1.0) -> Tensor:
+    """Fused Wqkv projection + RoPE on the q and k thirds: x [T,H] bf16, w [3H,H] bf16 -> qkv [T,3H] bf16 (rotated).
+    q_scale multiplies the rotated q third in fp32 before its bf16 rounding (SOFTMAX_Q_SCALE for `prescaled` attention)."""
     T, Kd = x.shape
     N = w.shape[0]
     out = _empty((T, N), torch.bfloat16, x)
-    call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos, torch.float32), ptr(sin, torch.float32), S, int(per_batch), 2 * N // 3, stream(),
+    call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos, torch.float32), ptr(sin, torch.float32), S, int(per_batch), 2 * N // 3, float(q_scale), stream(),
          tag=("gemm256_kernel" if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
          work=2.0 * T * N * Kd)
     return out
@@ -172,11 +176,12 @@ def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, 
     return qkv
 
 
-def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float):
+def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float, prescaled: bool = False):
+    """prescaled: the q third already carries scale * log2(e) (qkv_linear_rope(..., q_scale=SOFTMAX_Q_SCALE))."""
     out = torch.empty((B * S, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     keys = S if window < 0 else min(S, 2 * window + 1)
-    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, window, scale, stream(),
+    call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, window, scale, int(prescaled), stream(),
          tag="attn_fwd_kernel" + ("<global>" if window < 0 else "<local>"), work=4.0 * B * nh * S * keys * 64)
     return out, lse
 
@@ -185,7 +190,7 @@ ATTN_BWD_DQ, ATTN_BWD_DKV = 1, 2  # stages of cm3p_attn_bwd (include/cm3p_hip.h)
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
-             window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False) -> Tensor:
+             window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False, prescaled: bool = False) -> Tensor:
     """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM).
     The two kernels are issued as two C calls so that each has its own profiler tag (one rocprof row per tag).  `work` is the
     algorithmic count of SURVEY.md section 8(d) (backward = 2 x forward = four matmuls: dQ is the dq kernel's, dP / dV / dK the
@@ -198,23 +203,23 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     v = "3" if window < 0 else ""  # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip (names as rocprof shows them)
     for stage, name, products in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel", 1), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel", 3)):
         call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh,
-             window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, stream(), tag=name + kind,
+             window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, int(prescaled), stream(), tag=name + kind,
              work=2.0 * products * B * nh * S * keys * 64)
     return dqkv
 
 
-def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int, scale: float):
+def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int, scale: float, prescaled: bool = False):
     """Packed sequences: qkv [total, 3, nh, 64], cu int32 [B+1] -> out [total, nh*64], lse [nh, total]."""
     total = qkv.shape[0]
     out = torch.empty((total, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((nh, total), dtype=torch.float32, device=qkv.device)
-    call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(cu, torch.int32), B, max_s, total, nh, window, scale, stream(),
+    call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(cu, torch.int32), B, max_s, total, nh, window, scale, int(prescaled), stream(),
          tag="attn_fwd_kernel" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
     return out, lse
 
 
 def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int,
-                    scale: float, rope: Optional[tuple] = None) -> Tensor:
+                    scale: float, rope: Optional[tuple] = None, prescaled: bool = False) -> Tensor:
     """rope = (cos, sin) per packed token [total, 32]: also applies the inverse rotation to dq / dk."""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
@@ -223,7 +228,7 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     v = "3" if window < 0 else ""
     for stage, name in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel"), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel")):
         call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s,
-             qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, stream(), tag=name + kind)
+             qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, int(prescaled), stream(), tag=name + kind)
     return dqkv
 
 

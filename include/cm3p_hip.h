@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 8
+#define CM3P_ABI_VERSION 9
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -101,9 +101,13 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
  * bf16-rounded projection in fp32 while it stores the staged rows (what the reference's autocast path computes: rotary on the
  * bf16 linear output); the 128 x 128 kernel for small shapes rotates the fp32 accumulators before rounding.  Both are inside
  * the tolerance of the tests.  cos/sin: [n_pos, 32] fp32 from cm3p_rope_table; token row m uses table row m (per_batch != 0)
- * or m % S.  Heads are 64 wide; N and rope_cols are multiples of 64. */
+ * or m % S.  Heads are 64 wide; N and rope_cols are multiples of 64.
+ * q_scale: the first rope_cols / 2 columns (the q third) are multiplied by q_scale in fp32 BEFORE the single bf16 rounding of the
+ * rotated value.  With q_scale = scale * log2(e) the attention kernels (q_prescaled = 1) get scores that are already in the
+ * exp2 units of their softmax: no per-score multiply and no second rounding of q - the same number of roundings as the
+ * reference's path, which rounds the rotated q once and scales inside SDPA in fp32.  q_scale = 1 leaves q as the reference's. */
 int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, int64_t N, int64_t K, const float* cos_tab,
-                       const float* sin_tab, int S, int per_batch, int rope_cols, void* stream);
+                       const float* sin_tab, int S, int per_batch, int rope_cols, float q_scale, void* stream);
 
 /* Host-only: the split_k the library recommends for a weight-gradient GEMM of this shape (sizes the workspace). */
 int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K);
@@ -139,19 +143,24 @@ int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B
  *   qkv: [B, S, 3, nh, 64] bf16 (q and k already rotated);  out: [B, S, nh, 64] bf16;  lse: [B, nh, S] fp32
  *   (natural-log sum-exp of the scaled scores; +inf for rows with no visible key);  key_mask: [B, S] bytes or NULL.
  */
+/* q_prescaled != 0: the q third of qkv already holds q * scale * log2(e) (cm3p_qkv_gemm_rope with that q_scale); the kernels
+ * then skip the scaling.  q_prescaled == 0: plain q; the kernels apply scale * log2(e) in fp32 on the score accumulators (one
+ * extra multiply per score) - q is never re-rounded to bf16 either way.  `scale` is always the softmax scale (1 / sqrt(64)). */
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
-                  float scale, void* stream);
+                  float scale, int q_prescaled, void* stream);
 /* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten.
  * If cos_tab/sin_tab are not NULL the inverse rotary rotation is applied to dq and dk before they are stored (the
  * backward of apply_rotary_pos_emb), with pos_batch_stride = 0 (one position row for all batches) or S.
  * stages: which of the backward's kernels to launch - CM3P_ATTN_BWD_DQ (the dq third of dqkv, and delta),
  * CM3P_ATTN_BWD_DKV (the dk and dv thirds; reads the delta a DQ stage wrote earlier on the same stream), or both (3).
- * Callers that time kernels one by one issue the stages as two calls; the results are identical. */
+ * Callers that time kernels one by one issue the stages as two calls; the results are identical.
+ * dqkv's q third is the gradient w.r.t. the UN-scaled rotated q in both q_prescaled modes (the chain rule through q_scale is
+ * applied inside), i.e. what the Wqkv GEMM's backward expects. */
 #define CM3P_ATTN_BWD_DQ 1
 #define CM3P_ATTN_BWD_DKV 2
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
-                  const float* sin_tab, int64_t pos_batch_stride, int stages, void* stream);
+                  const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GeGLU: g = gelu_erf(h[:, :I]) * h[:, I:]   (ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91).
@@ -263,10 +272,10 @@ int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, vo
  * cm3p_gather_rows_f32: dst[i, :] = src[idx[i], :];  cm3p_scatter_rows_f32: dst[idx[i], :] = src[i, :] (dst pre-zeroed by the
  * caller = _pad_cm3p_output); rows of H fp32 values, H % 4 == 0. */
 int cm3p_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* cu_seqlens, int B, int max_seqlen, int64_t total,
-                         int nh, int window, float scale, void* stream);
+                         int nh, int window, float scale, int q_prescaled, void* stream);
 int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                          const int* cu_seqlens, int B, int max_seqlen, int64_t total, int nh, int window, float scale,
-                         const float* cos_tab, const float* sin_tab, int stages, void* stream);
+                         const float* cos_tab, const float* sin_tab, int stages, int q_prescaled, void* stream);
 int cm3p_gather_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
 int cm3p_scatter_rows_f32(const float* src, const int64_t* idx, float* dst, int64_t n, int H, void* stream);
 

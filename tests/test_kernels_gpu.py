@@ -248,6 +248,11 @@ def test_fused_qkv_rope_gemm_and_inverse_in_attention_backward(K, T, S, nh, per_
     got = K.qkv_linear_rope(x, w, cos, sin, S, per_batch)
     _assert_close(got, ref, 2e-2, 1.6e-2, "fused qkv rope")
     assert torch.equal(got.view(T, 3, H)[:, 2], ref.view(T, 3, H)[:, 2])  # v third untouched and bit-identical
+    # q_scale: only the q third changes - by that factor, applied before the rounding (so within one bf16 ulp of c * q)
+    c = K.SOFTMAX_Q_SCALE
+    got_s = K.qkv_linear_rope(x, w, cos, sin, S, per_batch, q_scale=c)
+    assert torch.equal(got_s.view(T, 3, H)[:, 1:], got.view(T, 3, H)[:, 1:])
+    _assert_close(got_s.view(T, 3, H)[:, 0], got.view(T, 3, H)[:, 0].float() * c, 1e-3, 1.0e-2, "q third scaled")
 
     qkv = got
     do = _bf(torch.randn(T, H, generator=g)).to(DEV)
@@ -300,26 +305,38 @@ def test_pooling(K, cls, use_mask):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True):
+def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True, prescaled=False):
+    """prescaled: the kernels are handed q * scale * log2(e) rounded ONCE to bf16 (what the Wqkv GEMM's epilogue produces) and the
+    reference runs on exactly that q divided back in fp32 - both modes are held to the same tolerance."""
     from oracle import cm3p_oracle as O
 
     g = torch.Generator().manual_seed(seed)
     qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g))
+    c = K.SOFTMAX_Q_SCALE
+    qkv_dev = qkv.clone()
+    if prescaled:
+        qkv_dev[:, :, 0] = _bf(qkv[:, :, 0].float() * c)  # one rounding of the scaled q
+        qkv = qkv_dev.clone()
+        qkv[:, :, 0] = (qkv_dev[:, :, 0].float() / c)  # the reference's q (fp32, not representable in bf16: kept as float below)
     mask = None
     if lens is not None:
         mask = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).long()
     allowed = O.attention_allowed(mask, B, S, window if window >= 0 else None)
     if allowed is None and window >= 0:
         allowed = torch.ones(B, 1, S, S, dtype=torch.bool)
-    x = qkv.float().requires_grad_(True)
+    x = qkv.float()
+    if prescaled:
+        x[:, :, 0] = qkv_dev[:, :, 0].float() / c
+    x.requires_grad_(True)
     q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
     o = O.sdpa(q, k, v, allowed, 0.125, eager=True).transpose(1, 2).reshape(B * S, nh * 64)
     do = _bf(torch.randn(B * S, nh * 64, generator=g))
     o.backward(do.float())
 
     km = mask.to(torch.uint8).to(DEV) if mask is not None else None
-    out, lse = K.attn_fwd(qkv.to(DEV), km, B, S, nh, window, 0.125)
-    _assert_close(out, o.detach().to(torch.bfloat16), 4e-3, 2e-2, f"attn fwd S={S} w={window}")  # q is pre-scaled in bf16
+    out, lse = K.attn_fwd(qkv_dev.to(DEV), km, B, S, nh, window, 0.125, prescaled=prescaled)
+    # 2e-3: q is never re-rounded to bf16 by the kernels (r01 pre-scaled it in bf16 and needed 4e-3)
+    _assert_close(out, o.detach().to(torch.bfloat16), 2e-3, 2e-2, f"attn fwd S={S} w={window} prescaled={prescaled}")
     # rows with no visible key are exact zeros
     if allowed is not None:
         dead = ~allowed.any(dim=-1).expand(B, nh, S).transpose(1, 2).reshape(B * S, nh)  # (B*S, nh)
@@ -327,8 +344,8 @@ def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True):
             assert out.view(B * S, nh, 64).cpu()[dead].abs().max().item() == 0.0
             assert torch.isinf(lse.cpu().transpose(1, 2).reshape(B * S, nh)[dead]).all()
     if check_bwd:
-        dqkv = K.attn_bwd(qkv.to(DEV), out, do.to(DEV), lse, km, B, S, nh, window, 0.125)
-        want = x.grad
+        dqkv = K.attn_bwd(qkv_dev.to(DEV), out, do.to(DEV), lse, km, B, S, nh, window, 0.125, prescaled=prescaled)
+        want = x.grad  # (dq is the gradient w.r.t. the un-scaled q in both modes)
         scale = want.abs().max().item()
         _assert_close(dqkv, want, 2e-2 * scale, 3e-2, f"attn bwd S={S} w={window}")
         for i, nm in enumerate("qkv"):
@@ -338,6 +355,12 @@ def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True):
 
 def test_attention_global_nopad(K):
     _attn_case(K, 2, 256, 2, -1, None, 1)
+
+
+@pytest.mark.parametrize("window,lens,S", [(-1, None, 256), (-1, [203, 100, 7], 203), (64, None, 512), (64, [300, 64, 1], 300)])
+def test_attention_with_prescaled_q(K, window, lens, S):
+    """The model's mode: q carries scale * log2(e) from the Wqkv GEMM's epilogue (one rounding), the kernels skip the scaling."""
+    _attn_case(K, 2 if lens is None else 3, S, 2, window, lens, 11, prescaled=True)
 
 
 def test_attention_global_padded_ragged(K):
