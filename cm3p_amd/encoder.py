@@ -359,7 +359,7 @@ class CM3PEncoder(nn.Module):
     def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 position_ids: Optional[Tensor] = None, inputs_embeds: Optional[Tensor] = None,
                 audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None, unpad: bool = False,
-                output_hidden_states: bool = False):
+                output_hidden_states: bool = False, cu_seqlens: Optional[Tensor] = None, max_seqlen: Optional[int] = None):
         """-> last_hidden_state (B, S, H) fp32 [, tuple of L+1 detached hidden states (the stack's input and every layer's output,
         TF:...modeling_modernbert.py:457-470) when output_hidden_states].  Exactly one of input_ids / inputs_embeds.
 
@@ -369,6 +369,8 @@ class CM3PEncoder(nn.Module):
         cfg = self.config
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if cu_seqlens is not None:
+            return self._forward_prepacked(input_ids, position_ids, audio_slot, audio_rows, cu_seqlens, max_seqlen, output_hidden_states)
         if input_ids is not None and input_ids.dtype != torch.int64:
             input_ids = input_ids.to(torch.int64)  # nn.Embedding takes IntTensor or LongTensor; the kernels index with int64
         ref = input_ids if input_ids is not None else inputs_embeds
@@ -402,6 +404,20 @@ class CM3PEncoder(nn.Module):
         else:
             x0 = _LayerNormFn.apply(inputs_embeds.reshape(B * S, H), self.embeddings.norm.weight, cfg.norm_eps)
 
+        y, hiddens = self._run_stack(x0, B, S, attention_mask, position_ids, packed, output_hidden_states, dev)
+        if hiddens is not None:
+            if packed is not None:
+                hiddens = [K.scatter_rows(h[:n_valid].contiguous(), idx, B * S) for h in hiddens]
+            hiddens = tuple(h.view(B, S, H) for h in hiddens)
+        if packed is not None:
+            y = _PadRowsFn.apply(y, idx, n_valid, B * S)
+        y = y.view(B, S, H)
+        return (y, hiddens) if output_hidden_states else y
+
+    def _run_stack(self, x0: Tensor, B: int, S: int, attention_mask, position_ids, packed, output_hidden_states: bool, dev):
+        """The L encoder layers + final norm on [rows, H]; `packed` = (idx, cu, max_s, n_valid, n_rows, pos) for unpadded execution."""
+        cfg = self.config
+        H = cfg.hidden_size
         geo = _Geometry()
         geo.B, geo.S, geo.H, geo.I, geo.nh, geo.L = B, S, H, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         geo.eps = cfg.norm_eps
@@ -411,6 +427,7 @@ class CM3PEncoder(nn.Module):
         geo.checkpoint = bool(self.gradient_checkpointing and self.training)
         geo.max_s = S
         if packed is not None:
+            idx, cu, max_s, n_valid, n_rows, pos = packed
             geo.B = cu.numel() - 1  # (+1 when alignment rows form a pseudo-sequence)
             geo.S = max_s
             geo.cu, geo.max_s = cu, max_s
@@ -443,14 +460,54 @@ class CM3PEncoder(nn.Module):
             if hiddens is not None:
                 hiddens.append(x.detach())
         y = _FinalNormFn.apply(geo, x, self.final_norm.weight)
-        if hiddens is not None:
-            if packed is not None:
-                hiddens = [K.scatter_rows(h[:n_valid].contiguous(), idx, B * S) for h in hiddens]
-            hiddens = tuple(h.view(B, S, H) for h in hiddens)
-        if packed is not None:
-            y = _PadRowsFn.apply(y, idx, n_valid, B * S)
-        y = y.view(B, S, H)
-        return (y, hiddens) if output_hidden_states else y
+        return y, hiddens
+
+    def _forward_prepacked(self, input_ids: Tensor, position_ids: Optional[Tensor], audio_slot, audio_rows, cu_seqlens: Tensor,
+                           max_seqlen: Optional[int], output_hidden_states: bool):
+        """Caller-supplied unpadded inputs (ref:cm3p/modeling_cm3p.py:911-931 when `indices` / `cu_seqlens` / `max_seqlen` are given;
+        the layout of _unpad_cm3p_input, :65-104): input_ids (total,), cu_seqlens (batch + 1,) -> last_hidden_state (total, H),
+        NOT re-padded (the reference's encoder leaves caller-packed rows packed as well)."""
+        cfg = self.config
+        if input_ids is None or input_ids.dim() != 1:
+            raise ValueError("with cu_seqlens, input_ids must be the 1-D unpadded token tensor (total_nnz,)")
+        if not input_ids.is_cuda:
+            raise RuntimeError("cm3p_amd runs on MI355X only: inputs must be CUDA/HIP tensors (no CPU fallback)")
+        dev = input_ids.device
+        ids = input_ids.to(torch.int64).contiguous()
+        total = ids.numel()
+        cu = cu_seqlens.to(device=dev, dtype=torch.int32).contiguous()
+        lens = cu[1:] - cu[:-1]
+        # ONE host read validates the description (a wrong cu_seqlens would send the kernels past the rows)
+        last, mx, mn = torch.stack((cu[-1], lens.max(), lens.min())).tolist()
+        if int(cu[0]) != 0 or last != total or mn <= 0:
+            raise ValueError(f"cu_seqlens must start at 0, increase strictly and end at the token count ({total}); got end {last}, min length {mn}")
+        max_s = int(mx) if max_seqlen is None else int(max_seqlen)
+        if max_s < mx:
+            raise ValueError(f"max_seqlen {max_s} is smaller than the longest sequence ({mx})")
+        n_rows = (total + 63) // 64 * 64  # alignment rows: one pseudo-sequence of pad tokens, no gradient flows into it
+        if position_ids is None:
+            pos = torch.arange(total, device=dev) - torch.repeat_interleave(cu[:-1].to(torch.int64), lens.to(torch.int64))
+        else:
+            pos = position_ids.reshape(-1).to(torch.int64)
+            if pos.numel() != total:
+                raise ValueError("position_ids must be unpadded like input_ids")
+        slot_p = audio_slot
+        if n_rows != total:
+            ids = torch.cat((ids, ids.new_zeros(n_rows - total)))
+            pos = torch.cat((pos, torch.arange(n_rows - total, device=dev)))
+            cu = torch.cat((cu, cu.new_full((1,), n_rows)))
+            if slot_p is not None:
+                slot_p = torch.cat((slot_p, slot_p.new_full((n_rows - total,), -1)))
+        pad = self.embeddings.tok_embeddings.padding_idx
+        x0 = _EmbedLNFn.apply(ids, self.embeddings.tok_embeddings.weight, self.embeddings.norm.weight, cfg.norm_eps,
+                              -1 if pad is None else pad, None if slot_p is None else slot_p.contiguous(), audio_rows)
+        packed = (None, cu, max(max_s, n_rows - total), total, n_rows, pos.contiguous())
+        y, hiddens = self._run_stack(x0, cu.numel() - 1, max_s, None, None, packed, output_hidden_states, dev)
+        if n_rows != total:
+            y = y[:total]
+            if hiddens is not None:
+                hiddens = [h[:total] for h in hiddens]
+        return (y, tuple(hiddens)) if output_hidden_states else y
 
     @staticmethod
     def _plan_unpadded(mask: Tensor, position_ids: Optional[Tensor]):

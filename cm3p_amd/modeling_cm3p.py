@@ -391,7 +391,20 @@ class CM3PMetadataTransformer(nn.Module):
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
         if indices is not None or cu_seqlens is not None:
-            raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
+            # caller-supplied unpadded rows (ref:cm3p/modeling_cm3p.py:359-372): the encoder runs packed; the reference has no pooling
+            # for them in this tower (ref:cm3p/modeling_cm3p.py:383-384)
+            if cu_seqlens is None:
+                raise ValueError("unpadded inputs need cu_seqlens (and max_seqlen)")
+            if output_attentions:
+                raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
+            _require_gpu(input_ids, "input_ids")
+            h = self.encoder(input_ids=input_ids, cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, output_hidden_states=bool(output_hidden_states))
+            hiddens = None
+            if output_hidden_states:
+                h, hiddens = h
+            if output_pooler:
+                raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
+            return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=None, hidden_states=hiddens, attentions=None)
         if output_attentions:
             raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         _require_gpu(input_ids, "input_ids")
@@ -470,12 +483,40 @@ class CM3PBeatmapTransformer(nn.Module):
                 attention_mask: Optional[Tensor] = None, sliding_window_mask=None, position_ids: Optional[Tensor] = None,
                 inputs_embeds: Optional[Tensor] = None, indices=None, cu_seqlens=None, max_seqlen=None, batch_size=None,
                 seq_len=None, output_attentions=None, output_hidden_states=None, output_pooler: bool = True) -> CM3PBeatmapModelOutput:
-        if indices is not None or cu_seqlens is not None:
-            raise NotImplementedError("unpadded (indices / cu_seqlens) inputs are not part of this build; pass padded batches")
         if output_attentions:
             raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         audio_out = None
         ohs = bool(output_hidden_states)
+        if indices is not None or cu_seqlens is not None:
+            # Caller-supplied unpadded rows (ref:cm3p/modeling_cm3p.py:911-931 with indices / cu_seqlens / max_seqlen given, layout of
+            # _unpad_cm3p_input :65-104): input_ids (total_nnz,), last_hidden_state stays (total_nnz, H), CLS pooling reads row
+            # cu_seqlens[:-1] of it (:624-627); mean pooling of unpadded rows is not implemented in the reference either (:628-629).
+            if cu_seqlens is None:
+                raise ValueError("unpadded inputs need cu_seqlens (and max_seqlen)")
+            if inputs_embeds is not None:
+                raise NotImplementedError("unpadded inputs_embeds are not supported; pass unpadded input_ids")
+            _require_gpu(input_ids, "input_ids")
+            slot = rows = None
+            if input_features is not None:
+                audio_out = self.audio_encoder(input_features)
+                rows = audio_out.audio_embeds
+                slot, count = K.audio_slots(input_ids.contiguous().view(-1).to(torch.int64), int(self.config.audio_token_id))
+                n = int(count.item())
+                if n != rows.shape[0]:
+                    raise RuntimeError(f"shape mismatch: {n} audio placeholder tokens but {rows.shape[0]} audio embeddings")
+            h = self.encoder(input_ids=input_ids, position_ids=position_ids, audio_slot=slot, audio_rows=rows, cu_seqlens=cu_seqlens,
+                             max_seqlen=max_seqlen, output_hidden_states=ohs)
+            hiddens = None
+            if ohs:
+                h, hiddens = h
+            pooled = None
+            if output_pooler:
+                if not self.config.cls_embed:
+                    raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
+                first = cu_seqlens[:-1].to(device=h.device, dtype=torch.int64).contiguous()
+                pooled = _TakeRowsFn.apply(h, first)
+            return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=None,
+                                          audio_model_output=audio_out)
         if inputs_embeds is not None:
             if input_features is not None:
                 raise NotImplementedError("input_features together with inputs_embeds is not supported")
@@ -636,8 +677,8 @@ class CM3PModel(CM3PPreTrainedModel):
                 self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
             beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
                                                  position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
-                                                 cu_seqlens=cu_seqlens, output_attentions=output_attentions,
-                                                 output_hidden_states=output_hidden_states)
+                                                 cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, batch_size=batch_size, seq_len=seq_len,
+                                                 output_attentions=output_attentions, output_hidden_states=output_hidden_states)
             beatmap_embeds = _L2NormFn.apply(_ProjectFn.apply(beatmap_outputs.pooler_output, self.beatmap_projection.weight))
             if self.gather_negatives and metadata_ids is not None:
                 if metadata_ids.dim() == 2:
@@ -683,16 +724,25 @@ class CM3PModel(CM3PPreTrainedModel):
             if beatmap_outputs is None:
                 raise ValueError("output_logits needs input_ids")
             hs = beatmap_outputs.last_hidden_state
-            Bq, Sq, Hq = hs.shape
             V = self.config.beatmap_config.vocab_size
-            head_args = (hs.reshape(Bq * Sq, Hq), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
+            head_args = (hs.reshape(-1, hs.size(-1)), self.head.dense.weight, self.head.dense.bias, self.head.norm.weight,
                          self.decoder.weight, self.decoder.bias, self.config.beatmap_config.norm_eps)
             mlm = None
             if labels is not None and return_loss:
                 lp, mlm = _MLMHeadLossFn.apply(*head_args, labels, kwargs.get("num_items_in_batch"))
             else:
                 lp = _MLMHeadFn.apply(*head_args)
-            logits = lp.view(Bq, Sq, -1)[..., :V]
+            if hs.dim() == 3:
+                logits = lp.view(hs.size(0), hs.size(1), -1)[..., :V]
+            else:
+                # caller-supplied unpadded rows: logits (total_nnz, V), re-padded like the reference's flash_attention_2 branch
+                # (_pad_cm3p_output, ref:cm3p/modeling_cm3p.py:999-1001) when the padded geometry was given
+                logits = lp[:, :V]
+                if indices is not None and batch_size is not None and seq_len is not None:
+                    # (detached, as the reference re-pads under no_grad when labels are given; the loss was taken on the packed rows)
+                    idx64 = indices.to(device=lp.device, dtype=torch.int64).contiguous()
+                    padded = K.scatter_rows(lp.detach().contiguous(), idx64, int(batch_size) * int(seq_len))
+                    logits = padded.view(int(batch_size), int(seq_len), -1)[..., :V]
             if mlm is not None:
                 if torch.is_tensor(loss):
                     loss = _AddScaledFn.apply(loss, mlm, 0.5)

@@ -190,6 +190,20 @@ def test_gather_negatives_world_size_one_equals_local_loss():
         assert torch.allclose(out0.logits_per_beatmap, out1.logits_per_beatmap, atol=1e-6)
         assert _rel(model.beatmap_model.encoder.layers[0].attn.Wqkv.weight.grad, g0) <= 5e-3  # bf16 re-rounding of grads
         assert abs(model.logit_scale.grad.item() - s0.item()) <= 1e-4
+        # DistributedDataParallel over RCCL with the bf16 gradient-compression hook (bench.py --grad-compress bf16 halves the
+        # 545 MB fp32 all-reduce): same gradients up to one bf16 rounding
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+        model.zero_grad(set_to_none=True)
+        for p in model.beatmap_model.audio_encoder.parameters():
+            p.requires_grad_(False)  # no input_features in this case: DDP needs every trainable parameter to get a gradient
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()], bucket_cap_mb=1)
+        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+        out2 = ddp(**_inputs(blob))
+        out2.loss.backward()
+        torch.cuda.synchronize()
+        g2 = model.beatmap_model.encoder.layers[0].attn.Wqkv.weight.grad
+        assert torch.isfinite(g2).all() and _rel(g2, g0) <= 1e-2
     finally:
         dist.destroy_process_group()
 
@@ -289,6 +303,60 @@ def test_unpadded_execution_matches_the_reference_fixture(name):
             assert _rel(g, v) <= 6e-2, f"{k}: rel L2 {_rel(g, v):.3e}"
         checked += 1
     assert checked >= 10
+
+
+def _unpad_like_the_reference(ids, mask):
+    """_unpad_cm3p_input (ref:cm3p/modeling_cm3p.py:88-104) restated: -> unpadded ids, indices, cu_seqlens, max_seqlen."""
+    lens = mask.sum(dim=-1, dtype=torch.int32)
+    indices = torch.nonzero(mask.flatten(), as_tuple=False).flatten()
+    cu = torch.nn.functional.pad(torch.cumsum(lens, dim=0, dtype=torch.int32), (1, 0))
+    return ids.flatten()[indices], indices, cu, int(lens.max())
+
+
+@pytest.mark.parametrize("name", ["d64_audio", "d64_cls_nopad"])
+def test_caller_supplied_unpadded_inputs(name):
+    """The reference's forward also takes inputs the CALLER has unpadded (input_ids (total_nnz,), indices, cu_seqlens, max_seqlen,
+    batch_size, seq_len; ref:cm3p/modeling_cm3p.py:911-931): same loss / embeddings as the padded fixture, last_hidden_state stays
+    (total_nnz, H), CLS pooling reads rows cu_seqlens[:-1] (:624-627)."""
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    inp = _inputs(blob)
+    ids_u, indices, cu, max_s = _unpad_like_the_reference(inp["input_ids"], inp["attention_mask"])
+    B, S = inp["input_ids"].shape
+    model = _build(name)
+    extra = {k: v for k, v in inp.items() if k not in ("input_ids", "attention_mask")}
+    out = model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=max_s, batch_size=B, seq_len=S, **extra)
+    assert abs(out.loss.item() - blob["loss"].item()) <= 3e-2, (out.loss.item(), blob["loss"].item())
+    assert _rel(out.beatmap_embeds, blob["beatmap_embeds"]) <= 2e-2
+    assert _rel(out.logits_per_metadata, blob["logits_per_metadata"]) <= 3e-2
+    h = out.beatmap_model_output.last_hidden_state
+    assert h.shape == (ids_u.numel(), CASES[name]["cfg"]["beatmap_config"]["hidden_size"])
+    if "beatmap_last_hidden_state" in blob:
+        want = blob["beatmap_last_hidden_state"][blob["in.attention_mask"].bool()]
+        assert _rel(h, want) <= 2e-2
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for k, v in blob.items():
+        if k.startswith("grad.") and v.norm() >= 1e-8:
+            assert _rel(params[k[5:]].grad, v) <= 6e-2, k
+            checked += 1
+    assert checked >= 8
+    # malformed descriptions are refused on the host (they would send the kernels past the rows)
+    with pytest.raises(ValueError):
+        model(input_ids=ids_u, indices=indices, cu_seqlens=cu[:-1], max_seqlen=max_s, batch_size=B, seq_len=S, **extra)
+    with pytest.raises(ValueError):
+        model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=1, batch_size=B, seq_len=S, **extra)
+
+
+def test_caller_supplied_unpadded_inputs_with_mean_pooling_raise_like_the_reference():
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    inp = _inputs(blob)
+    ids_u, indices, cu, max_s = _unpad_like_the_reference(inp["input_ids"], inp["attention_mask"])
+    model = _build(name)
+    with pytest.raises(NotImplementedError, match="Pooling with unpadded input"):
+        model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=max_s, metadata_ids=inp["metadata_ids"],
+              metadata_attention_mask=inp["metadata_attention_mask"])
 
 
 def test_unpadded_and_padded_paths_agree_and_full_batches_stay_padded():
