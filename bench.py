@@ -109,7 +109,7 @@ def pmc_value(kind: str, workload: str, tag: str):
         d = json.load(open(os.path.join(ROOT, rel)))
     except Exception:
         return None, None
-    for key in (tag, tag.split("<")[0]):  # exact tag first, then the kernel name without its <global>/<local> suffix
+    for key in (tag, tag.split(" [")[0], tag.split("<")[0]):  # exact tag, the kernel name without its " [global]" note, the bare name
         if key in d:
             v = d[key]
             return ((v.get("busy_frac", v.get("mfma_util"))) if isinstance(v, dict) else v), rel

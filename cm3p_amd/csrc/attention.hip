@@ -65,10 +65,13 @@ constexpr int kFwdStage = 8192 + 8192 + 64 + 16;  // K image R, V image T, mask 
 // PRE: the q third already holds q * scale * log2(e) (cm3p_qkv_gemm_rope's q_scale): the MFMA delivers scores in exp2 units and the
 // reference point rides in as the initial accumulator.  !PRE: plain q; scale * log2(e) and the reference point are applied by one
 // fp32 v_fma per score - q is never re-rounded to bf16.
-template <int QSUB, bool PRE>
+// BAND: sliding-window layers (window >= 0); the global instance (window = -1 at compile time) carries no band arithmetic and
+// shows up as its own row in a profile.
+template <int QSUB, bool PRE, bool BAND>
 __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                                         float* __restrict__ lse, const uint8_t* __restrict__ kmask,
-                                                                        int Smax, int nh, int window, float scale, VarLen vl) {
+                                                                        int Smax, int nh, int window_arg, float scale, VarLen vl) {
+    const int window = BAND ? window_arg : -1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QW = 32 * QSUB;  // queries per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
@@ -622,8 +625,15 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t
     // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
     // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    if (pre) attn_fwd_kernel<1, true><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
-    else attn_fwd_kernel<1, false><<<grid, 256, 2 * kFwdStage, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl);
+#define CM3P_FWD_ARGS (const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, window, scale, vl
+    if (window >= 0) {
+        if (pre) attn_fwd_kernel<1, true, true><<<grid, 256, 2 * kFwdStage, s>>>(CM3P_FWD_ARGS);
+        else attn_fwd_kernel<1, false, true><<<grid, 256, 2 * kFwdStage, s>>>(CM3P_FWD_ARGS);
+    } else {
+        if (pre) attn_fwd_kernel<1, true, false><<<grid, 256, 2 * kFwdStage, s>>>(CM3P_FWD_ARGS);
+        else attn_fwd_kernel<1, false, false><<<grid, 256, 2 * kFwdStage, s>>>(CM3P_FWD_ARGS);
+    }
+#undef CM3P_FWD_ARGS
     return CM3P_OK;
 }
 

@@ -170,6 +170,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         reinterpret_cast<float*>(st__ + 16384)[tid & 127] = sreg__; /* (threads 128..255 repeat the same values) */   \
     } while (0)
 
+    // The same two blocks cut into five pieces each, so that a tile's staging rides in the gaps of the MFMA stream (one piece per
+    // chunk of a step) instead of sitting in front of it: piece I of the stores / of the loads.
+#define CM3P_LSTORE_PIECE(P, st_, I)                                                                                     \
+    do {                                                                                                                  \
+        char* st__ = (st_);                                                                                               \
+        if constexpr ((I) == 0) *reinterpret_cast<uint4*>(st__ + oW0) = P##q0;                                            \
+        if constexpr ((I) == 1) *reinterpret_cast<uint4*>(st__ + oW1) = P##q1;                                            \
+        if constexpr ((I) == 2) *reinterpret_cast<uint4*>(st__ + 8192 + oW0) = P##g0;                                     \
+        if constexpr ((I) == 3) *reinterpret_cast<uint4*>(st__ + 8192 + oW1) = P##g1;                                     \
+        if constexpr ((I) == 4) {                                                                                         \
+            const float sreg__ = (tid & 64) ? (P##ok ? -P##raw : 0.f) : (P##ok ? P##raw * lse_mul : kNegInf);             \
+            reinterpret_cast<float*>(st__ + 16384)[tid & 127] = sreg__;                                                   \
+        }                                                                                                                 \
+    } while (0)
+#define CM3P_GLOAD_PIECE(P, t_, I)                                                                                       \
+    do {                                                                                                                  \
+        const int t__ = (t_);                                                                                             \
+        const int r0 = min(t__ * 64 + srow, S - 1), r1 = min(t__ * 64 + 32 + srow, S - 1);                                 \
+        if constexpr ((I) == 0) P##q0 = *reinterpret_cast<const uint4*>(qbase + (int64_t)r0 * ld + schunk);               \
+        if constexpr ((I) == 1) P##q1 = *reinterpret_cast<const uint4*>(qbase + (int64_t)r1 * ld + schunk);               \
+        if constexpr ((I) == 2) P##g0 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r0 * ldo + schunk);             \
+        if constexpr ((I) == 3) P##g1 = *reinterpret_cast<const uint4*>(dobase + (int64_t)r1 * ldo + schunk);             \
+        if constexpr ((I) == 4) {                                                                                         \
+            const int q__ = t__ * 64 + (tid & 63);                                                                        \
+            P##raw = stat_src[min(q__, S - 1)];                                                                           \
+            P##ok = q__ < S;                                                                                              \
+        }                                                                                                                 \
+    } while (0)
+
     // register-resident LDS fragments of the current 32-query block
     bf16x8 Qf[4], Gf[4];     // rows of Q / dO (A operands of the score products)
     bf16x8 gT[2][2], qT[2][2];  // [sp][db]: dO^T / Q^T (A operands of the gradient products)
@@ -205,12 +234,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
     // of block X, then the gradient products of block X (key block KBX).  KBY == 1: Y is the last user of the resident row
     // fragments, which are reloaded for the next query block from `nS` / `nSi` right behind the MFMAs that read them.
     // KBX == 1: X is the last user of the resident transposed fragments, reloaded from `nG` the same way.
+    // `hook(chunk)` is called once in each of the 16 chunks (integral_constant 0..15), behind the chunk's MFMA: the tile's staging
+    // pieces ride there.
     auto step = [&](auto kbx_c, auto kby_c, f32x16& Xs, f32x16& Xdp, f32x16& Ys, f32x16& Ydp, const char* nS, const char* nSi,
-                    const char* nG) {
+                    const char* nG, auto&& hook) {
         constexpr int KBX = decltype(kbx_c)::value, KBY = decltype(kby_c)::value;
+#define CM3P_HOOK(C) hook(std::integral_constant<int, (C)>{})
         CM3P_SB();
         mfma_vc(Ys, Qf[0], kf[KBY][0], isv);
         exp2_pair<PRE>(Xs, 0, cm);
+        CM3P_HOOK(0);
         CM3P_SB();
         mfma_vc(Ydp, Gf[0], vf[KBY][0], idv);
         exp2_pair<PRE>(Xs, 2, cm);
@@ -219,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
             Gf[0] = ld_frag(nS + 8192 + oR[0]);
             load_init(nSi, isv, 0, 0);
         }
+        CM3P_HOOK(1);
         CM3P_SB();
         SC_ACC(Ys, Qf[1], kf[KBY][1], isv);
         exp2_pair<PRE>(Xs, 4, cm);
@@ -226,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
             load_init(nSi, isv, 0, 1);
             Qf[1] = ld_frag(nS + oR[1]);
         }
+        CM3P_HOOK(2);
         CM3P_SB();
         SC_ACC(Ydp, Gf[1], vf[KBY][1], idv);
         exp2_pair<PRE>(Xs, 6, cm);
@@ -233,6 +268,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
             Gf[1] = ld_frag(nS + 8192 + oR[1]);
             load_init(nSi, idv, 1, 0);
         }
+        CM3P_HOOK(3);
         CM3P_SB();
         SC_ACC(Ys, Qf[2], kf[KBY][2], isv);
         exp2_pair<PRE>(Xs, 8, cm);
@@ -240,18 +276,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
             Qf[2] = ld_frag(nS + oR[2]);
             load_init(nSi, idv, 1, 1);
         }
+        CM3P_HOOK(4);
         CM3P_SB();
         SC_ACC(Ydp, Gf[2], vf[KBY][2], idv);
         exp2_pair<PRE>(Xs, 10, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[2] = ld_frag(nS + 8192 + oR[2]);
+        CM3P_HOOK(5);
         CM3P_SB();
         SC_ACC(Ys, Qf[3], kf[KBY][3], isv);
         exp2_pair<PRE>(Xs, 12, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Qf[3] = ld_frag(nS + oR[3]);
+        CM3P_HOOK(6);
         CM3P_SB();
         SC_ACC(Ydp, Gf[3], vf[KBY][3], idv);
         exp2_pair<PRE>(Xs, 14, cm);
         if constexpr (KBY == 1 && !(CM3P_ABL & 4)) Gf[3] = ld_frag(nS + 8192 + oR[3]);
+        CM3P_HOOK(7);
         CM3P_SB();
         // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS
 #if CM3P_ABL & 32
@@ -264,34 +304,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         dv[0][KBX] = mfma32(gT[0][0], pf0, dv[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 0);
         CM3P_VALU(_Pragma("unroll") for (int i = 0; i < 4; ++i) Xdp[i] *= Xs[i];)
+        CM3P_HOOK(8);
         CM3P_SB();
         dv[1][KBX] = mfma32(gT[0][1], pf0, dv[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 0);
         CM3P_VALU(_Pragma("unroll") for (int i = 4; i < 8; ++i) Xdp[i] *= Xs[i];)
         CM3P_VALU(const bf16x8 ds0 = acc_to_frag(Xdp, 0);)
+        CM3P_HOOK(9);
         CM3P_SB();
         dk[0][KBX] = mfma32(qT[0][0], ds0, dk[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 0, 1);
         CM3P_VALU(const bf16x8 pf1 = acc_to_frag(Xs, 1);)
+        CM3P_HOOK(10);
         CM3P_SB();
         dk[1][KBX] = mfma32(qT[0][1], ds0, dk[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 0, 1, 1);
         CM3P_VALU(_Pragma("unroll") for (int i = 8; i < 12; ++i) Xdp[i] *= Xs[i];)
+        CM3P_HOOK(11);
         CM3P_SB();
         dv[0][KBX] = mfma32(gT[1][0], pf1, dv[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 0, 0);
         CM3P_VALU(_Pragma("unroll") for (int i = 12; i < 16; ++i) Xdp[i] *= Xs[i];)
         CM3P_VALU(const bf16x8 ds1 = acc_to_frag(Xdp, 1);)
+        CM3P_HOOK(12);
         CM3P_SB();
         dv[1][KBX] = mfma32(gT[1][1], pf1, dv[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 1, 0);
+        CM3P_HOOK(13);
         CM3P_SB();
         dk[0][KBX] = mfma32(qT[1][0], ds1, dk[0][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 0, 1);
+        CM3P_HOOK(14);
         CM3P_SB();
         dk[1][KBX] = mfma32(qT[1][1], ds1, dk[1][KBX]);
         if constexpr (KBX == 1 && !(CM3P_ABL & 4)) loadG_one(nG, 1, 1, 1);
+        CM3P_HOOK(15);
         CM3P_SB();
+#undef CM3P_HOOK
     };
 
     f32x16 sA, dpA, sB, dpB;
@@ -302,21 +351,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const uint16_t* _
         constexpr int SL = decltype(slot_c)::value, NS = (SL + 1) % kSlots3;
         const char* st = smem + SL * kBwdStage;
         char* nst = smem + NS * kBwdStage;
-        // tile t+1 sits in the staging set of ITS parity since the top of tile t-1; tile t+3 takes the set over
-        // (the slot's last readers finished tile t-3 before the previous barrier)
-        if constexpr (!(CM3P_ABL & 2)) {
-            if constexpr (SL & 1) CM3P_LSTORE(a, nst);
-            else CM3P_LSTORE(b, nst);
-        }
+        // Tile t+1 sits in the staging set of ITS parity since tile t-1 and is stored to its slot (whose last readers finished
+        // tile t-3) piece by piece in the score chunks of step 1; the barrier between steps 1 and 2 publishes it just before step 2
+        // starts reading it; the loads of tile t+3 then take the set over, piece by piece in the gradient chunks of step 2.
+        auto no_hook = [&](auto) {};
+        auto store_hook = [&](auto c) {
+            constexpr int C = decltype(c)::value;
+            if constexpr (!(CM3P_ABL & 2) && C < 5) {
+                if constexpr (SL & 1) CM3P_LSTORE_PIECE(a, nst, C);
+                else CM3P_LSTORE_PIECE(b, nst, C);
+            }
+        };
+        auto load_hook = [&](auto c) {
+            constexpr int C = decltype(c)::value;
+            if constexpr (!(CM3P_ABL & 2) && C >= 8 && C < 13) {
+                if constexpr (SL & 1) CM3P_GLOAD_PIECE(a, t + 3, C - 8);
+                else CM3P_GLOAD_PIECE(b, t + 3, C - 8);
+            }
+        };
+        step(I0{}, I1{}, sA, dpA, sB, dpB, st + 4096, st + 128, nullptr, no_hook);     // X = (qb0, kb0), Y = (qb0, kb1); row fragments -> qb1
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, st + 4096, store_hook);  // X = (qb0, kb1), Y = (qb1, kb0); transposed -> qb1
         if constexpr (!(CM3P_ABL & 1)) __syncthreads();
-        if constexpr (!(CM3P_ABL & 2)) {
-            if constexpr (SL & 1) CM3P_GLOAD(a, t + 3);
-            else CM3P_GLOAD(b, t + 3);
-        }
-        step(I0{}, I1{}, sA, dpA, sB, dpB, st + 4096, st + 128, nullptr);   // X = (qb0, kb0), Y = (qb0, kb1); row fragments -> qb1
-        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, st + 4096);    // X = (qb0, kb1), Y = (qb1, kb0); transposed -> qb1
-        step(I0{}, I1{}, sA, dpA, sB, dpB, nst, nst, nullptr);              // X = (qb1, kb0), Y = (qb1, kb1); row fragments -> next tile
-        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, nst);          // X = (qb1, kb1), Y = next tile's (qb0, kb0)
+        step(I0{}, I1{}, sA, dpA, sB, dpB, nst, nst, nullptr, load_hook);              // X = (qb1, kb0), Y = (qb1, kb1); row fragments -> next tile
+        step(I1{}, I0{}, sB, dpB, sA, dpA, nullptr, nullptr, nst, no_hook);            // X = (qb1, kb1), Y = next tile's (qb0, kb0)
     };
 
     // prologue: tile 0 in slot 0, tile 1 in flight, fragments of (tile 0, qb0), scores of its first block

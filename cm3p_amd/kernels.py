@@ -182,11 +182,18 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
     lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     keys = S if window < 0 else min(S, 2 * window + 1)
     call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, window, scale, int(prescaled), stream(),
-         tag="attn_fwd_kernel" + ("<global>" if window < 0 else "<local>"), work=4.0 * B * nh * S * keys * 64)
+         tag=_attn_tag("attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>"), window, prescaled), work=4.0 * B * nh * S * keys * 64)
     return out, lse
 
 
 ATTN_BWD_DQ, ATTN_BWD_DKV = 1, 2  # stages of cm3p_attn_bwd (include/cm3p_hip.h)
+
+
+def _attn_tag(fmt: str, window: int, prescaled: bool, varlen: bool = False) -> str:
+    """Profiler tag = the kernel's name as rocprofv3 prints it (the template argument is the q_prescaled mode) + which layers it
+    served: "attn_bwd_dkv3_kernel<true> [global]".  bench.py matches the part before " [" against the rocprof / PMC rows."""
+    name = fmt % ("true" if prescaled else "false") if "%s" in fmt else fmt
+    return f"{name} [{'global' if window < 0 else 'local'}{', varlen' if varlen else ''}]"
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
@@ -199,11 +206,11 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
-    kind = "<global>" if window < 0 else "<local>"
-    v = "3" if window < 0 else ""  # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip (names as rocprof shows them)
-    for stage, name, products in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel", 1), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel", 3)):
+    # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip; sliding-window layers: the band kernels of attention.hip
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    for stage, name, products in ((ATTN_BWD_DQ, names[0], 1), (ATTN_BWD_DKV, names[1], 3)):
         call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh,
-             window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, int(prescaled), stream(), tag=name + kind,
+             window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, int(prescaled), stream(), tag=_attn_tag(name, window, prescaled),
              work=2.0 * products * B * nh * S * keys * 64)
     return dqkv
 
@@ -214,7 +221,7 @@ def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window
     out = torch.empty((total, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((nh, total), dtype=torch.float32, device=qkv.device)
     call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(cu, torch.int32), B, max_s, total, nh, window, scale, int(prescaled), stream(),
-         tag="attn_fwd_kernel" + ("<global,varlen>" if window < 0 else "<local,varlen>"))
+         tag=_attn_tag("attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>"), window, prescaled, True))
     return out, lse
 
 
@@ -224,11 +231,10 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
-    kind = "<global,varlen>" if window < 0 else "<local,varlen>"
-    v = "3" if window < 0 else ""
-    for stage, name in ((ATTN_BWD_DQ, f"attn_bwd_dq{v}_kernel"), (ATTN_BWD_DKV, f"attn_bwd_dkv{v}_kernel")):
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    for stage, name in ((ATTN_BWD_DQ, names[0]), (ATTN_BWD_DKV, names[1])):
         call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s,
-             qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, int(prescaled), stream(), tag=name + kind)
+             qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, int(prescaled), stream(), tag=_attn_tag(name, window, prescaled, True))
     return dqkv
 
 

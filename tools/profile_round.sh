@@ -2,15 +2,17 @@
 # GPU box: the rocprofv3 passes whose summaries are committed under profiles/ (run from the repository root).
 #   bash tools/profile_round.sh r01
 # 1. kernel trace + stats of the judged command; 2. FETCH_SIZE, 3. WRITE_SIZE and 4. matrix-pipe busy cycles in separate counter-only passes
-# Every pass runs under its own timeout (a counter pass once sat silent until the box watchdog ended the call).
+# Every pass runs under its own timeout: in r01 one counter pass sat silent until the box watchdog ended the call; the logs of that
+# call were not kept, so its cause could not be established afterwards (profiles/README.md).  Always `-- python3 <file>`: a script
+# started through its shebang would re-exec under the profiler.
 # (MI355X_MICROARCH.md: never combine --pmc with other trace domains), turned into HBM bytes per launch by tools/pmc_traffic.py.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optimizer --no-secondary"
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o out -- $CMD > $OUT/stats.log 2>&1
 timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o out -- $CMD > $OUT/fetch.log 2>&1
 timeout -k 10 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o out -- $CMD > $OUT/write.log 2>&1
