@@ -14,12 +14,13 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_RETURNS_INT64 = {"cm3p_attn_bwd_fused_workspace_bytes"}  # size queries that do not fit an int
 
 # name -> argtypes, mirrors include/cm3p_hip.h one to one
 SIGNATURES = {
@@ -70,6 +71,8 @@ SIGNATURES = {
     "cm3p_sum_f32": [_P, _P, _L, _F, _I, _P],
     "cm3p_pointwise_loss": [_P, _P, _P, _P, _L, _I, _P],
     "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _I, _P],
+    "cm3p_attn_bwd_fused_workspace_bytes": [_I, _I, _I],
+    "cm3p_attn_bwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _L, _I, _I, _P, _L, _P],
     "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _I, _P],
     "cm3p_gather_rows_f32": [_P, _P, _P, _L, _I, _P],
     "cm3p_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
@@ -102,7 +105,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name in _RETURNS_INT64 else c_int
     if lib.cm3p_abi_version() != ABI_VERSION:
         raise Cm3pHipError(f"ABI mismatch: library {lib.cm3p_abi_version()} vs binding {ABI_VERSION}; rebuild")
     _lib = lib

@@ -4,6 +4,7 @@ No autograd here and no torch compute ops: everything numerical happens inside l
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -14,7 +15,8 @@ from ._lib import BF16, EPI_BF16, EPI_F32, EPI_F32_RESID, F32, call, dt, ptr, qu
 Tensor = torch.Tensor
 
 # C-ABI calls whose `work` is algorithmic BYTES (HBM-bound row-wise kernels); every other `work` is matmul FLOPs
-_lib.HBM_BOUND_TAGS.update({"cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd"})
+_lib.HBM_BOUND_TAGS.update({"cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd", "attn_bwd_prep_kernel [global]",
+                            "attn_bwd_dq_reduce_kernel [global]", "attn_bwd_prep_kernel [global, varlen]", "attn_bwd_dq_reduce_kernel [global, varlen]"})
 
 
 def _empty(shape, dtype, like: Tensor) -> Tensor:
@@ -196,12 +198,48 @@ def _attn_tag(fmt: str, window: int, prescaled: bool, varlen: bool = False) -> s
     return f"{name} [{'global' if window < 0 else 'local'}{', varlen' if varlen else ''}]"
 
 
+ATTN_BWD_FUSED_PREP, ATTN_BWD_FUSED_MAIN, ATTN_BWD_FUSED_REDUCE = 1, 2, 4  # stages of cm3p_attn_bwd_fused
+_fused_ws: dict = {}  # (device index, stream) -> byte tensor: the fused backward's workspace, grown on demand, shared by all layers
+
+
+def attn_bwd_fused_enabled() -> bool:
+    """Global layers run the five-product kernel of csrc/attention_bwd_fused.hip unless CM3P_ATTN_BWD_FUSED=0 (then the
+    query-parallel + key-parallel pair of csrc/attention_bwd.hip; same results up to bf16 rounding of partial sums)."""
+    return os.environ.get("CM3P_ATTN_BWD_FUSED", "1") != "0"
+
+
+def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, rope, per_batch, prescaled) -> Tensor:
+    dqkv = torch.empty_like(qkv)
+    cos, sin = rope if rope is not None else (None, None)
+    need = query("cm3p_attn_bwd_fused_workspace_bytes", B, S, nh)
+    key = (qkv.device.index, torch.cuda.current_stream(qkv.device).cuda_stream)
+    ws = _fused_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _fused_ws[key] = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    varlen = cu is not None
+    rows = total if varlen else B * S
+    fl = 2.0 * B * nh * S * S * 64  # one S x S x 64 product per (batch, head); SURVEY.md 8(d) credits four to the backward
+    slabs = float(need)
+    for stage, name, work in (
+        (ATTN_BWD_FUSED_PREP, "attn_bwd_prep_kernel", 2.0 * rows * nh * 64 * 2 + 12.0 * rows * nh),
+        (ATTN_BWD_FUSED_MAIN, "attn_bwd_fused_kernel<%s>", 4.0 * fl),
+        (ATTN_BWD_FUSED_REDUCE, "attn_bwd_dq_reduce_kernel", slabs + rows * nh * 64 * 2.0),
+    ):
+        call("cm3p_attn_bwd_fused", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(dqkv), ptr(key_mask, torch.uint8),
+             ptr(cu, torch.int32), B, S, total if varlen else 0, nh, scale, ptr(cos, torch.float32), ptr(sin, torch.float32),
+             S if (per_batch and not varlen) else 0, stage, int(prescaled), ptr(ws), ws.numel(), stream(),
+             tag=_attn_tag(name, -1, prescaled, varlen), work=work)
+    return dqkv
+
+
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
              window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False, prescaled: bool = False) -> Tensor:
     """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM).
     The two kernels are issued as two C calls so that each has its own profiler tag (one rocprof row per tag).  `work` is the
     algorithmic count of SURVEY.md section 8(d) (backward = 2 x forward = four matmuls: dQ is the dq kernel's, dP / dV / dK the
     dkv kernel's); the scores each kernel recomputes are not credited."""
+    if window < 0 and attn_bwd_fused_enabled():
+        return _attn_bwd_fused(qkv, out, dout, lse, key_mask, None, B, S, 0, nh, scale, rope, per_batch, prescaled)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
@@ -228,6 +266,8 @@ def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window
 def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int,
                     scale: float, rope: Optional[tuple] = None, prescaled: bool = False) -> Tensor:
     """rope = (cos, sin) per packed token [total, 32]: also applies the inverse rotation to dq / dk."""
+    if window < 0 and attn_bwd_fused_enabled():
+        return _attn_bwd_fused(qkv, out, dout, lse, None, cu, B, max_s, qkv.shape[0], nh, scale, rope, False, prescaled)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 9
+#define CM3P_ABI_VERSION 10
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -161,6 +161,25 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
                   const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream);
+
+/* The same backward for GLOBAL layers (no window) as one key-parallel kernel that executes each of the five matrix products
+ * once (cm3p_attn_bwd with window < 0 runs a query-parallel and a key-parallel kernel that both recompute the scores: seven).
+ * Padded batches: cu_seqlens = NULL, total = 0, S = the padded length, key_mask [B, S] or NULL, lse [B, nh, S].
+ * Unpadded batches: cu_seqlens [B + 1], S = max_seqlen, total rows, key_mask NULL, pos_batch_stride 0, lse [nh, total], rotary
+ * tables per token (as cm3p_attn_bwd_varlen).
+ * stages: CM3P_ATTN_BWD_FUSED_PREP (delta and the per-tile score offsets -> workspace), _MAIN (dk and dv thirds of dqkv; one bf16
+ * partial dq per 256-key block -> workspace), _REDUCE (the dq third of dqkv from the partials, summed in fp32 in a fixed order:
+ * deterministic); a caller issues all three in this order on one stream (7), or one by one to time them.
+ * workspace: caller-owned device memory of at least cm3p_attn_bwd_fused_workspace_bytes(B, S, nh) bytes, 16-byte aligned;
+ * contents are scratch (nothing is carried between calls). */
+#define CM3P_ATTN_BWD_FUSED_PREP 1
+#define CM3P_ATTN_BWD_FUSED_MAIN 2
+#define CM3P_ATTN_BWD_FUSED_REDUCE 4
+int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh);
+int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* key_mask,
+                        const int* cu_seqlens, int B, int S, int64_t total, int nh, float scale, const float* cos_tab,
+                        const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GeGLU: g = gelu_erf(h[:, :I]) * h[:, I:]   (ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91).

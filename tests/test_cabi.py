@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, "include", "cm3p_hip.h")
 def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(cm3p_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(cm3p_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +45,7 @@ def test_binding_table_matches_header(lib_path):
     # argument counts in the binding equal the parameter counts in the header
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for name, argtypes in _lib.SIGNATURES.items():
-        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        m = re.search(r"\b(?:int|int64_t)\s+" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
         assert m, name
         params = m.group(1).strip()
         n = 0 if params in ("", "void") else params.count(",") + 1
@@ -57,6 +57,8 @@ def test_host_only_queries(lib_path):
 
     assert _lib.query("cm3p_pool_chunks", 4096) == 32
     assert 1 <= _lib.query("cm3p_layernorm_bwd_blocks", 131072) <= 2048
+    # 64-bit size query: the C2 workspace of the fused attention backward is past 2^31 bytes
+    assert _lib.query("cm3p_attn_bwd_fused_workspace_bytes", 32, 4096, 12) == 32 * 12 * (76 * 512 + 16 * 4160 * 128)
 
 
 def test_cpu_tensors_are_refused(lib_path):
