@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
                                                                 int nh, float scale, const float* __restrict__ rope_cos,
                                                                 const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (tells the compiler that everything derived from it is wave-uniform)
     const int nkb = (Smax + 255) / 256, NT = (Smax + 63) / 64;
     int kblk, head, b;
     decode_block(nkb, nh, kblk, head, b);
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
                         uint2{pack_bf16x2(dq[4 * g], dq[4 * g + 1]), pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3])};
             }
             if constexpr (C == 6) {
+                asm volatile("" ::: "memory");  // (the uint2 stores above and these uint4 loads do not alias by type: keep their order)
                 zr0 = *reinterpret_cast<const uint4*>(smem + zR);
                 zr1 = *reinterpret_cast<const uint4*>(smem + zR + 16 * 80);
             }

@@ -357,6 +357,60 @@ def test_attention_global_nopad(K):
     _attn_case(K, 2, 256, 2, -1, None, 1)
 
 
+@pytest.mark.parametrize("impl", ["fused", "pair"])
+@pytest.mark.parametrize("S,lens,prescaled", [(700, [700, 513, 64], True), (1536, None, True), (330, [330, 257, 1], False), (64, None, False)])
+def test_attention_global_backward_both_implementations(K, monkeypatch, impl, S, lens, prescaled):
+    """Global layers have two backward implementations behind one call: the five-product kernel (attention_bwd_fused.hip, the
+    default) and the query-parallel + key-parallel pair (attention_bwd.hip, CM3P_ATTN_BWD_FUSED=0).  Both are held to the same
+    tolerance against the fp32 reference, over several 256-key blocks, ragged padding and both q modes."""
+    monkeypatch.setenv("CM3P_ATTN_BWD_FUSED", "1" if impl == "fused" else "0")
+    _attn_case(K, 2 if lens is None else 3, S, 2, -1, lens, 21, prescaled=prescaled)
+
+
+def test_attention_fused_backward_matches_pair_and_is_deterministic(K, monkeypatch):
+    B, S, nh = 3, 1100, 3
+    g = torch.Generator().manual_seed(5)
+    qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g)).to(DEV)
+    do = _bf(torch.randn(B * S, nh * 64, generator=g)).to(DEV)
+    km = (torch.arange(S)[None] < torch.tensor([1100, 777, 300])[:, None]).to(torch.uint8).to(DEV)
+    out, lse = K.attn_fwd(qkv, km, B, S, nh, -1, 0.125)
+    monkeypatch.setenv("CM3P_ATTN_BWD_FUSED", "1")
+    a = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, -1, 0.125)
+    a2 = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, -1, 0.125)
+    monkeypatch.setenv("CM3P_ATTN_BWD_FUSED", "0")
+    b = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, -1, 0.125)
+    assert torch.equal(a, a2)  # partial dq slabs are summed in a fixed order
+    for i, (nm, tol) in enumerate((("dq", 6e-3), ("dk", 1e-4), ("dv", 1e-6))):  # dq: one extra bf16 rounding per 256-key partial
+        x, y = a[:, :, i].float(), b[:, :, i].float()
+        assert ((x - y).norm() / y.norm()).item() < tol, nm
+    # rows of padded keys: dk = dv = 0 exactly, in both
+    dead = (km == 0).view(B, S)
+    assert a[:, :, 1:][dead].abs().max().item() == 0.0 and b[:, :, 1:][dead].abs().max().item() == 0.0
+
+
+def test_attention_fused_backward_masked_keys_with_unbounded_scores(K, monkeypatch):
+    """Keys under the padding mask are not bounded by the row maximum (lse covers visible keys only): with large K rows there,
+    exp2(s - lse) overflows.  The fused kernel clamps p to [0, 1] and stores such keys as zero rows of its K image, so they
+    contribute exact zeros to dq and get dk = dv = 0."""
+    monkeypatch.setenv("CM3P_ATTN_BWD_FUSED", "1")
+    B, S, nh = 2, 520, 2
+    g = torch.Generator().manual_seed(6)
+    qkv = torch.randn(B, S, 3, nh, 64, generator=g)
+    lens = torch.tensor([520, 301])
+    mask = torch.arange(S)[None] < lens[:, None]
+    big = qkv.clone()
+    big[:, :, 1][~mask] *= 200.0  # masked keys: scores of several thousand
+    do = _bf(torch.randn(B * S, nh * 64, generator=g)).to(DEV)
+    km = mask.to(torch.uint8).to(DEV)
+    res = []
+    for t in (qkv, big):
+        x = _bf(t).to(DEV)
+        out, lse = K.attn_fwd(x, km, B, S, nh, -1, 0.125)
+        res.append(K.attn_bwd(x, out, do, lse, km, B, S, nh, -1, 0.125))
+    assert torch.isfinite(res[1].float()).all()
+    assert torch.equal(res[0], res[1])  # the masked keys' content is irrelevant, bit for bit
+
+
 @pytest.mark.parametrize("window,lens,S", [(-1, None, 256), (-1, [203, 100, 7], 203), (64, None, 512), (64, [300, 64, 1], 300)])
 def test_attention_with_prescaled_q(K, window, lens, S):
     """The model's mode: q carries scale * log2(e) from the Wqkv GEMM's epilogue (one rounding), the kernels skip the scaling."""

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--padded", action="store_true", help="right-pad every second row to 3/4 of the length (key mask path)")
     ap.add_argument("--arms", default="fused,pair,band")
+    ap.add_argument("--window", type=int, default=-1, help="sliding-window layers: |q - k| <= window (arms fused / band only)")
     ap.add_argument("--plain-q", action="store_true", help="q_prescaled = 0 kernels (the model runs the prescaled ones)")
     args = ap.parse_args()
     B, S, nh = args.batch, args.seq, 12
@@ -45,9 +46,11 @@ def main():
     inv = 1.0 / (160000.0 ** (torch.arange(0, 64, 2, dtype=torch.float) / 64)).to(DEV)
     rope = K.rope_table(pos.contiguous(), inv)
     pre = not args.plain_q
-    out, lse = K.attn_fwd(qkv, mask, B, S, nh, -1, 0.125, pre)
+    out, lse = K.attn_fwd(qkv, mask, B, S, nh, args.window, 0.125, pre)
     all_arms = {"fused": (-1, "1"), "pair": (-1, "0"), "band": (S, "0")}
-    arms = {k: all_arms[k] for k in args.arms.split(",")}
+    if args.window >= 0:
+        all_arms = {"fused": (args.window, "1"), "band": (args.window, "0")}
+    arms = {k: all_arms[k] for k in args.arms.split(",") if k in all_arms}
 
     def run(name):
         w, fused = arms[name]
@@ -72,7 +75,7 @@ def main():
             run(name)
             for tag, (n, ms, work) in _lib.profile_end().items():
                 times[name].setdefault(tag.split("<")[0].split(" [")[0], []).append(ms)
-    fl = 2.0 * B * nh * S * S * 64
+    fl = 2.0 * B * nh * S * (S if args.window < 0 else min(S, 2 * args.window + 1)) * 64
     for name in arms:
         tot = 0.0
         for tag, v in times[name].items():
