@@ -228,7 +228,7 @@ def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, r
         call("cm3p_attn_bwd_fused", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(dqkv), ptr(key_mask, torch.uint8),
              ptr(cu, torch.int32), B, S, total if varlen else 0, nh, scale, ptr(cos, torch.float32), ptr(sin, torch.float32),
              S if (per_batch and not varlen) else 0, stage, int(prescaled), ptr(ws), ws.numel(), stream(),
-             tag=_attn_tag(name, -1, prescaled, varlen), work=work)
+             tag=_attn_tag(name, -1, prescaled, varlen), work=None if varlen else work)  # (packed rows: S is only the longest sequence)
     return dqkv
 
 
