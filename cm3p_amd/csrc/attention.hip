@@ -22,6 +22,10 @@
 
 #include "attn_common.h"
 
+#ifndef CM3P_BABL
+#define CM3P_BABL 0  // timing-only ablations of attn_bwd_dkv_kernel: 1 no products, 2 no epilogue, 4 no tile DMA
+#endif
+
 namespace {
 
 __device__ __forceinline__ float reg_max16(const f32x16& a) {  // 8 x v_max3_f32
@@ -42,6 +46,25 @@ __device__ __forceinline__ void mask_scores_keyrows(f32x16& s, const uint8_t* ma
         for (int r = 0; r < 4; ++r) {
             const int key = key0 + kl + r;
             const bool ok = (((mb >> (8 * r)) & 0xffu) != 0u) & (key >= lo) & (key <= hi);
+            s[4 * g + r] = ok ? s[4 * g + r] : kNegInf;
+        }
+    }
+}
+
+// The same for the LDS-DMA staged kernels: one validity DWORD per key (the mask byte zero-extended; MASK == false: no mask was
+// given), keys past the sequence are cut by `hi` (the caller clamps it to S - 1).
+template <bool MASK>
+__device__ __forceinline__ void mask_scores_keyrows_d(f32x16& s, const uint32_t* maskd, int blk, int key0, int lo, int hi, int hh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int kl = 32 * blk + 8 * g + 4 * hh;
+        uint4 mb = uint4{1u, 1u, 1u, 1u};
+        if constexpr (MASK) mb = *reinterpret_cast<const uint4*>(maskd + kl);
+        const uint32_t m[4] = {mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kl + r;
+            const bool ok = (m[r] != 0u) & (key >= lo) & (key <= hi);
             s[4 * g + r] = ok ? s[4 * g + r] : kNegInf;
         }
     }
@@ -238,21 +261,11 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
     for (int u = 0; u < QSUB; ++u) {
         const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        if (qrow[u] < S) {
-            uint16_t* orow = out + (sv.row0 + qrow[u]) * nh * 64 + head * 64;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int dv = 32 * blk + 8 * g + 4 * hh;
-                    const uint2 w = {pack_bf16x2(oacc[u][blk][4 * g] * inv, oacc[u][blk][4 * g + 1] * inv),
-                                     pack_bf16x2(oacc[u][blk][4 * g + 2] * inv, oacc[u][blk][4 * g + 3] * inv)};
-                    *reinterpret_cast<uint2*>(orow + dv) = w;
-                }
-            if (hh == 0)
-                lse[sv.stat0 + qrow[u]] =
-                    l_tot > 0.f ? (mc_run[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
-        }
+        // (the loop's last barrier is behind every wave: the stages are free and serve as the waves' transposition buffers)
+        store_rows32(smem + 4608 * wid, oacc[u][0], oacc[u][1], inv, out + (sv.row0 + q0 + 32 * u) * nh * 64 + head * 64, (int64_t)nh * 64,
+                     S - (q0 + 32 * u), lane);
+        if (qrow[u] < S && hh == 0)
+            lse[sv.stat0 + qrow[u]] = l_tot > 0.f ? (mc_run[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
     }
 }
 
@@ -260,9 +273,10 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 // dQ (and delta[b, h, q] = sum_d dO[q, d] * O[q, d], which it computes for its own rows and publishes for the dK/dV kernel):
 // same geometry as the forward.  LDS per stage: K image (row + transposed reads) + V image + mask bytes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDqStage = 2 * 8192 + 64 + 16;  // K image, V image, mask bytes, all-valid flag
+constexpr int kDqStage = 2 * 8192 + 256;  // K image, V image, one validity dword per key
+constexpr int kDqSlots = 4;               // LDS-DMA ring: tile t+3 is requested while tile t is consumed
 
-template <bool PRE>
+template <bool PRE, bool MASK>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                              const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
                                                              float* __restrict__ delta,
@@ -271,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                                                              const float* __restrict__ rope_cos,
                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qblk, head, b;
     decode_block((Smax + 127) / 128, nh, qblk, head, b);
     const int Q0 = qblk * 128;
@@ -286,9 +301,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const int64_t ldo = (int64_t)nh * 64;
     const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
 
+    const int Q1 = min(S, Q0 + 128) - 1;
+    int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
+    if (window >= 0) {
+        klo = max(0, Q0 - window);
+        khi = min(S - 1, Q1 + window);
+        wlo = max(0, q0 - window);
+        whi = min(S - 1, q0 + 31 + window);
+    }
+    const bool wave_live = q0 < S;
+    const int t_lo = klo / 64, t_hi = khi / 64;
+
+    // K / V tiles (and the keys' validity bytes) by LDS-DMA into a four-slot ring: three tiles in flight per workgroup instead of
+    // one - these kernels see at most five tiles, their time is the memory round trips, and the bytes in flight per CU set the
+    // bandwidth they reach.  Every wave issues the same operations per tile (ND), which is what the counted vmcnt wait relies on.
+    constexpr int ND = MASK ? 5 : 4;
+    const TileDma dma(wid, lane);
+    const int ldb = (int)ld * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t m0_k = __builtin_amdgcn_readfirstlane(lds0 + 2048u * wid);
+    const uint8_t* km = MASK ? kmask + sv.row0 : nullptr;
+    auto dma_tile = [&](int t) {
+        const uint32_t slot = (uint32_t)((t - t_lo) & (kDqSlots - 1)) * kDqStage;
+        dma.rows(m0_k + slot, kbase, ldb, t * 64, S);
+        dma.rows(m0_k + slot + 8192u, vbase, ldb, t * 64, S);
+        if constexpr (MASK) dma_ubyte64(lds0 + slot + 16384u, km, (uint32_t)min(t * 64 + lane, S - 1));
+    };
+    for (int t = t_lo; t <= min(t_hi, t_lo + 2); ++t) dma_tile(t);
+    // (the tiles are on their way before the wave's own fragments are requested: the two round trips overlap)
     const int qrow = q0 + (lane & 31);
     const int qrow_c = qrow < S ? qrow : S - 1;
-    const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? INT_MAX : qrow + window;
+    const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? S - 1 : min(qrow + window, S - 1);  // (keys past S: cut here)
     const float c = scale * kLog2e;
     bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -315,17 +358,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         if (hh == 0 && qrow < S) delta[stat] = dlt;
     }
 
-    const int Q1 = min(S, Q0 + 128) - 1;
-    int klo = 0, khi = S - 1, wlo = 0, whi = S - 1;
-    if (window >= 0) {
-        klo = max(0, Q0 - window);
-        khi = min(S - 1, Q1 + window);
-        wlo = max(0, q0 - window);
-        whi = min(S - 1, q0 + 31 + window);
+    // the rotary rows of the epilogue are requested now: their round trip hides behind the key sweep instead of ending the kernel
+    f32x4 rcs[4], rsn[4];
+    if (rope_cos) {
+        const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow_c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rcs[g] = *reinterpret_cast<const f32x4*>(rope_cos + prow * 32 + 8 * g + 4 * hh);
+            rsn[g] = *reinterpret_cast<const f32x4*>(rope_sin + prow * 32 + 8 * g + 4 * hh);
+        }
     }
-    const bool wave_live = q0 < S;
-    const int t_lo = klo / 64, t_hi = khi / 64;
-
     f32x16 dq[2], lse_init, dlt_init;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -334,38 +376,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         dlt_init[i] = -dlt;
     }
 
-    TileRegs64 kr, vr;
-    uint8_t mraw = 1;
-    bool mok = false;
-    // (nothing here consumes a loaded value - see attn_bwd_dkv_kernel; the mask byte is judged in lstore())
-    auto gload = [&](int t) {
-        gload64(kr, kbase, ld, t * 64, S, tid);
-        gload64(vr, vbase, ld, t * 64, S, tid);
-        const int key = t * 64 + (tid & 63);
-        mok = key < S;
-        if (kmask) mraw = kmask[sv.row0 + min(max(key, 0), S - 1)];
-    };
-    auto lstore = [&](int stage) {
-        char* st = smem + stage * kDqStage;
-        lstore64_R(st, kr, tid);
-        lstore64_R(st + 8192, vr, tid);
-        if (tid < 64) {
-            const uint8_t mreg = mok ? mraw : (uint8_t)0;
-            reinterpret_cast<uint8_t*>(st + 16384)[tid] = mreg;
-            const unsigned long long valid = __ballot(mreg != 0);
-            if (tid == 0) *reinterpret_cast<int*>(st + 16448) = (valid == ~0ull) ? 1 : 0;
-        }
-    };
-
-    gload(t_lo);
-    lstore(0);
-    __syncthreads();
 
     for (int t = t_lo; t <= t_hi; ++t) {
-        const int stage = (t - t_lo) & 1;
-        const char* st = smem + stage * kDqStage;
-        const bool more = t < t_hi;
-        if (more) gload(t + 1);
+        const char* st = smem + ((t - t_lo) & (kDqSlots - 1)) * kDqStage;
+        dma_wait_barrier(ND * min(t_hi - t, 2));  // tile t has landed in every wave; the slot of tile t-1 is free
+        if (t + 3 <= t_hi) dma_tile(t + 3);
         const int key0 = t * 64;
         if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
             f32x16 sacc[2], dp[2];
@@ -382,10 +397,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                     dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp[blk]);
                 }
             }
-            if (!tile_unmasked(*reinterpret_cast<const int*>(st + 16448), key0, q0, window)) {
-                const uint8_t* mb = reinterpret_cast<const uint8_t*>(st + 16384);
-                mask_scores_keyrows(sacc[0], mb, 0, key0, lo, hi, hh);
-                mask_scores_keyrows(sacc[1], mb, 1, key0, lo, hi, hh);
+            const uint32_t* mb = reinterpret_cast<const uint32_t*>(st + 16384);
+            int all_valid = key0 + 63 < S;
+            if constexpr (MASK) all_valid = all_valid && __all(mb[lane] != 0u);
+            if (!tile_unmasked(all_valid, key0, q0, window)) {
+                mask_scores_keyrows_d<MASK>(sacc[0], mb, 0, key0, lo, hi, hh);
+                mask_scores_keyrows_d<MASK>(sacc[1], mb, 1, key0, lo, hi, hh);
             }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -401,36 +418,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                 dq[1] = mfma32(frag_T(st, 16 * s, 1, lane), dsf, dq[1]);
             }
         }
-        if (more) lstore(stage ^ 1);
-        __syncthreads();
     }
 
-    if (qrow < S) {
-        uint16_t* drow = dqkv + (sv.row0 + qrow) * ld + head * 64;
-        if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d+32 are the two accumulator blocks of this lane
-            const int64_t prow = sv.pos0(b, pos_batch_stride) + qrow;
+    if (rope_cos) {  // backward of apply_rotary_pos_emb (the transposed rotation): dims d / d+32 are the lane's two accumulator blocks
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 lo4 = {dq[0][4 * g], dq[0][4 * g + 1], dq[0][4 * g + 2], dq[0][4 * g + 3]};
-                f32x4 hi4 = {dq[1][4 * g], dq[1][4 * g + 1], dq[1][4 * g + 2], dq[1][4 * g + 3]};
-                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dq[0][4 * g + r] = lo4[r];
-                    dq[1][4 * g + r] = hi4[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = 32 * blk + 8 * g + 4 * hh;
-                const uint2 w = {pack_bf16x2(dq[blk][4 * g] * scale, dq[blk][4 * g + 1] * scale),
-                                 pack_bf16x2(dq[blk][4 * g + 2] * scale, dq[blk][4 * g + 3] * scale)};
-                *reinterpret_cast<uint2*>(drow + d) = w;
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = dq[0][4 * g + r], b0 = dq[1][4 * g + r];
+                dq[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
+                dq[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
             }
     }
+    lds_only_barrier();  // every wave is done with the ring: its slots become the waves' transposition buffers
+    store_rows32(smem + 4608 * wid, dq[0], dq[1], scale, dqkv + (sv.row0 + q0) * ld + head * 64, ld, S - q0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // dK^T, dV^T (64 x 32 each) in accumulators while the workgroup sweeps query tiles of 64 rows.
 // LDS per stage: Q image + dO image (8 KiB each, row and transposed reads) + -lse*log2(e) and -delta (64 floats each).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, -lse*log2e and -delta rows
+constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, the rows' lse and delta (raw, 64 floats each)
+constexpr int kDkvSlots = 4;               // LDS-DMA ring, as in the dq kernel
 
 template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                                                               const float* __restrict__ rope_cos,
                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     int kblk, head, b;
     decode_block((Smax + 127) / 128, nh, kblk, head, b);
     const int K0 = kblk * 128;
@@ -465,6 +468,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const float* lse_bh = lse + sv.stat0;
     const float* dlt_bh = delta + sv.stat0;
 
+    const int K1 = min(S, K0 + 128) - 1;
+    int qlo = 0, qhi = S - 1, wlo = 0, whi = S - 1;
+    if (window >= 0) {
+        qlo = max(0, K0 - window);
+        qhi = min(S - 1, K1 + window);
+        wlo = max(0, k0 - window);
+        whi = min(S - 1, k0 + 31 + window);
+    }
+    const bool wave_live = k0 < S;
+    const int t_lo = qlo / 64, t_hi = qhi / 64;
+
+    // Q / dO tiles and the rows' lse / delta by LDS-DMA into a four-slot ring (see attn_bwd_dq_kernel): four operations per wave
+    // and tile, six in wave 0, which also brings the two statistics rows (and, in the sequence's last tile, overwrites the rows
+    // past the end - read from row S - 1 - with lse = +inf, delta = 0 before the barrier publishes them: p = 0 there)
+    const int ND = wid == 0 ? 6 : 4;
+    const TileDma dma(wid, lane);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t m0_q = __builtin_amdgcn_readfirstlane(lds0 + 2048u * wid);
+    auto dma_tile = [&](int t) {
+        const uint32_t slot = (uint32_t)((t - t_lo) & (kDkvSlots - 1)) * kDkvStage;
+        dma.rows(m0_q + slot, qbase, (int)ld * 2, t * 64, S);
+        dma.rows(m0_q + slot + 8192u, dobase, (int)ldo * 2, t * 64, S);
+        if (wid == 0) {
+            const uint32_t so = (uint32_t)(min(t * 64 + lane, S - 1) * 4);
+            dma_dword64(lds0 + slot + 16384u, lse_bh, so);
+            dma_dword64(lds0 + slot + 16384u + 256u, dlt_bh, so);
+        }
+    };
+    for (int t = t_lo; t <= min(t_hi, (CM3P_BABL & 4) ? t_lo - 1 : t_lo + 2); ++t) dma_tile(t);
+    // (the tiles are on their way before the wave's own K / V fragments are requested: the two round trips overlap)
     const int krow = k0 + (lane & 31);
     const int krow_c = krow < S ? krow : S - 1;
     const float c = scale * kLog2e;
@@ -478,54 +511,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const bool keys_all_ok = __all(key_ok);
     const int lo = window < 0 ? INT_MIN : krow - window, hi = window < 0 ? INT_MAX : krow + window;
 
-    const int K1 = min(S, K0 + 128) - 1;
-    int qlo = 0, qhi = S - 1, wlo = 0, whi = S - 1;
-    if (window >= 0) {
-        qlo = max(0, K0 - window);
-        qhi = min(S - 1, K1 + window);
-        wlo = max(0, k0 - window);
-        whi = min(S - 1, k0 + 31 + window);
+    // the rotary rows of the epilogue are requested now: their round trip hides behind the query sweep
+    f32x4 rcs[4], rsn[4];
+    if (rope_cos) {
+        const int64_t prow = sv.pos0(b, pos_batch_stride) + krow_c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rcs[g] = *reinterpret_cast<const f32x4*>(rope_cos + prow * 32 + 8 * g + 4 * hh);
+            rsn[g] = *reinterpret_cast<const f32x4*>(rope_sin + prow * 32 + 8 * g + 4 * hh);
+        }
     }
-    const bool wave_live = k0 < S;
-    const int t_lo = qlo / 64, t_hi = qhi / 64;
-
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
 
-    TileRegs64 qr, gr;
-    float sraw = 0.f;
-    bool sok = false;
-    const float* stat_src = (tid & 64) ? dlt_bh : lse_bh;
-    // Nothing in gload() consumes a loaded value (the first use is in lstore(), a whole tile of compute later): an arithmetic
-    // instruction on the fresh load made the compiler wait for the memory round trip right here, every tile.
-    auto gload = [&](int t) {
-        gload64(qr, qbase, ld, t * 64, S, tid);
-        gload64(gr, dobase, ldo, t * 64, S, tid);
-        const int q = t * 64 + (tid & 63);
-        sok = q < S;
-        sraw = stat_src[min(max(q, 0), S - 1)];  // raw lse (tid & 64 == 0) or delta; clamped address, judged by `sok`
-    };
-    auto lstore = [&](int stage) {
-        char* st = smem + stage * kDkvStage;
-        lstore64_R(st, qr, tid);
-        lstore64_R(st + 8192, gr, tid);
-        // -lse in log2 units (rows past S contribute p = 0) and -delta
-        const float sreg = (tid & 64) ? (sok ? -sraw : 0.f) : (sok ? -sraw * (PRE ? kLog2e : 1.0f / scale) : kNegInf);
-        if (tid < 128) reinterpret_cast<float*>(st + 16384)[tid] = sreg;
-    };
-
-    gload(t_lo);
-    lstore(0);
-    __syncthreads();
+    // the score accumulators start at -lse * log2(e) (PRE) or -lse / scale, dP's at -delta; rows past the sequence at -inf (p = 0)
+    const float lse_mul = PRE ? -kLog2e : -1.0f / scale;
 
     for (int t = t_lo; t <= t_hi; ++t) {
-        const int stage = (t - t_lo) & 1;
-        const char* st = smem + stage * kDkvStage;
-        const bool more = t < t_hi;
-        if (more) gload(t + 1);
+        char* st = smem + ((t - t_lo) & (kDkvSlots - 1)) * kDkvStage;
         const int qt0 = t * 64;
-        if (wave_live && qt0 <= whi && qt0 + 63 >= wlo) {
+        dma_wait(ND * min(t_hi - t, 2));  // this wave's part of tile t has landed
+        if (wid == 0 && qt0 + lane >= S) {
+            reinterpret_cast<float*>(st + 16384)[lane] = __builtin_huge_valf();
+            reinterpret_cast<float*>(st + 16384 + 256)[lane] = 0.f;
+        }
+        lds_only_barrier();  // ... everyone's has; the slot of tile t-1 is free
+        if (!(CM3P_BABL & 4) && t + 3 <= t_hi) dma_tile(t + 3);
+        if (!(CM3P_BABL & 1) && wave_live && qt0 <= whi && qt0 + 63 >= wlo) {
             const float* nlse = reinterpret_cast<const float*>(st + 16384);
             const float* ndlt = nlse + 64;
 #pragma unroll
@@ -538,9 +551,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                     const f32x4 d = *reinterpret_cast<const f32x4*>(ndlt + 32 * qb + 8 * g + 4 * hh);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        sacc[4 * g + r] = a[r];
-                        dp[4 * g + r] = d[r];
+                        sacc[4 * g + r] = a[r] * lse_mul;
+                        dp[4 * g + r] = -d[r];
                     }
+
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -582,39 +596,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                 }
             }
         }
-        if (more) lstore(stage ^ 1);
-        __syncthreads();
     }
 
-    if (krow < S) {
-        uint16_t* dkrow = dqkv + (sv.row0 + krow) * ld + nh * 64 + head * 64;
-        uint16_t* dvrow = dkrow + nh * 64;
-        if (rope_cos) {
-            const int64_t prow = sv.pos0(b, pos_batch_stride) + krow;
+    if (rope_cos) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 lo4 = {dk[0][4 * g], dk[0][4 * g + 1], dk[0][4 * g + 2], dk[0][4 * g + 3]};
-                f32x4 hi4 = {dk[1][4 * g], dk[1][4 * g + 1], dk[1][4 * g + 2], dk[1][4 * g + 3]};
-                rope_rotate4<true>(lo4, hi4, rope_cos + prow * 32, rope_sin + prow * 32, 8 * g + 4 * hh);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dk[0][4 * g + r] = lo4[r];
-                    dk[1][4 * g + r] = hi4[r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = dk[0][4 * g + r], b0 = dk[1][4 * g + r];
+                dk[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
+                dk[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
             }
-        }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = 32 * blk + 8 * g + 4 * hh;
-                // PRE: the products were taken with q * scale * log2(e), so dK = ln(2) * accumulator
-                const float ks = PRE ? 0.69314718055994531f : scale;
-                *reinterpret_cast<uint2*>(dkrow + d) =
-                    uint2{pack_bf16x2(dk[blk][4 * g] * ks, dk[blk][4 * g + 1] * ks), pack_bf16x2(dk[blk][4 * g + 2] * ks, dk[blk][4 * g + 3] * ks)};
-                *reinterpret_cast<uint2*>(dvrow + d) =
-                    uint2{pack_bf16x2(dv[blk][4 * g], dv[blk][4 * g + 1]), pack_bf16x2(dv[blk][4 * g + 2], dv[blk][4 * g + 3])};
-            }
+    }
+    lds_only_barrier();  // every wave is done with the ring: its slots become the waves' transposition buffers
+    if (!(CM3P_BABL & 2)) {
+        // PRE: the products were taken with q * scale * log2(e), so dK = ln(2) * accumulator
+        uint16_t* dk0 = dqkv + (sv.row0 + k0) * ld + nh * 64 + head * 64;
+        store_rows32(smem + 4608 * wid, dk[0], dk[1], PRE ? 0.69314718055994531f : scale, dk0, ld, S - k0, lane);
+        store_rows32(smem + 4608 * wid, dv[0], dv[1], 1.0f, dk0 + nh * 64, ld, S - k0, lane);
     }
 }
 
@@ -658,15 +657,30 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     if (stages & CM3P_ATTN_BWD_DQ) {
 #define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        if (pre) attn_bwd_dq_kernel<true><<<grid, 256, 2 * kDqStage, s>>>(CM3P_DQ_ARGS);
-        else attn_bwd_dq_kernel<false><<<grid, 256, 2 * kDqStage, s>>>(CM3P_DQ_ARGS);
+        static const bool attr = [] {
+            const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>),
+                                reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>)};
+            for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSlots * kDqStage);
+            return true;
+        }();
+        (void)attr;
+        if (pre && key_mask) attn_bwd_dq_kernel<true, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
+        else if (pre) attn_bwd_dq_kernel<true, false><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
+        else if (key_mask) attn_bwd_dq_kernel<false, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
+        else attn_bwd_dq_kernel<false, false><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
 #undef CM3P_DQ_ARGS
         if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
     if (stages & CM3P_ATTN_BWD_DKV) {
 #define CM3P_DKV_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        if (pre) attn_bwd_dkv_kernel<true><<<grid, 256, 2 * kDkvStage, s>>>(CM3P_DKV_ARGS);
-        else attn_bwd_dkv_kernel<false><<<grid, 256, 2 * kDkvStage, s>>>(CM3P_DKV_ARGS);
+        static const bool attr2 = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
+            return true;
+        }();
+        (void)attr2;
+        if (pre) attn_bwd_dkv_kernel<true><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
+        else attn_bwd_dkv_kernel<false><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
 #undef CM3P_DKV_ARGS
     }
     return CM3P_OK;

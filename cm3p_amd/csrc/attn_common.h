@@ -150,4 +150,85 @@ __device__ __forceinline__ void mfma_v0(f32x16& d, const bf16x8& a, const bf16x8
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
 }
 
+
+// A 32 x 64 block held as two accumulator blocks (lane = row l31, half hh; register i of block blk = column
+// 32 blk + 8 (i >> 2) + 4 hh + (i & 3)) -> bf16 rows of a row-major matrix, through a wave-private LDS buffer of 32 x 144 bytes.
+// Stored straight from the accumulators a lane owns 4 consecutive columns of one row: eight 8-byte stores per lane, each
+// instruction touching 32 different lines.  From here: four 16-byte stores per lane, 8 whole 128-byte rows per instruction.
+// (The uint2 stores and uint4 loads do not alias by type, hence the compiler barrier; one wave's LDS operations execute in order.)
+__device__ __forceinline__ void store_rows32(char* buf, const f32x16& b0, const f32x16& b1, float mul, uint16_t* dst_row0, int64_t ld_elems,
+                                             int nrows_valid, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<uint2*>(buf + l31 * 144 + (8 * g + 4 * hh) * 2) =
+            uint2{pack_bf16x2(b0[4 * g] * mul, b0[4 * g + 1] * mul), pack_bf16x2(b0[4 * g + 2] * mul, b0[4 * g + 3] * mul)};
+        *reinterpret_cast<uint2*>(buf + l31 * 144 + (32 + 8 * g + 4 * hh) * 2) =
+            uint2{pack_bf16x2(b1[4 * g] * mul, b1[4 * g + 1] * mul), pack_bf16x2(b1[4 * g + 2] * mul, b1[4 * g + 3] * mul)};
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i;
+        const uint4 v = *reinterpret_cast<const uint4*>(buf + row * 144 + (lane & 7) * 16);
+        if (row < nrows_valid) *reinterpret_cast<uint4*>(dst_row0 + row * ld_elems + (lane & 7) * 8) = v;
+    }
+    asm volatile("" ::: "memory");
+}
+
+// ---- LDS-DMA staging of 64-row tiles by a four-wave workgroup (the sliding-window kernels of attention.hip) ---------------------
+// A [*, 64] bf16 matrix tile (64 rows x 128 bytes) goes to LDS as the swizzled image off_R / off_T read: wave w brings rows
+// 16 w .. 16 w + 15 as two 1-KiB pieces (global_load_lds_dwordx4: lane l's 16 bytes land at piece + 16 l = row l >> 3, chunk slot
+// l & 7, which must hold global chunk (l & 7) ^ swz(row): the swizzle is applied to the SOURCE address).  One m0 write serves
+// both pieces: the instruction offset moves the LDS address AND the global address, so the scalar base is kept 1 KiB low and
+// the first piece's offset 1 KiB high.  Issued as inline assembly on purpose (gemm256.hip: through the builtin the compiler drains
+// every outstanding DMA before the next LDS read); ordering is the caller's counted s_waitcnt vmcnt + workgroup barrier.
+struct TileDma {
+    int prow0, prow1, pc0, pc1;  // the lane's two rows inside the tile and its source chunk byte offsets
+    __device__ __forceinline__ TileDma(int wid, int lane) {
+        prow0 = 16 * wid + (lane >> 3);
+        prow1 = prow0 + 8;
+        pc0 = ((lane & 7) ^ swz(prow0)) << 4;
+        pc1 = ((lane & 7) ^ swz(prow1)) << 4;
+    }
+    // rows r0 + prow (clamped to limit - 1) of the matrix at `base` (row stride ldb BYTES) -> LDS address m0v (+ 2 KiB per wave
+    // already included by the caller)
+    __device__ __forceinline__ void rows(uint32_t m0v, const void* base, int ldb, int r0, int limit) const {
+        const uint32_t v0 = (uint32_t)(min(r0 + prow0, limit - 1) * ldb + pc0 + 1024);
+        const uint32_t v1 = (uint32_t)(min(r0 + prow1, limit - 1) * ldb + pc1);
+        const char* b = static_cast<const char*>(base) - 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" ::"s"(m0v), "v"(v0),
+                     "v"(v1), "s"(b)
+                     : "memory", "m0");
+    }
+};
+// 64 consecutive floats / bytes (one per lane, index clamped by the caller) -> 64 dwords at LDS address m0v (bytes zero-extended)
+__device__ __forceinline__ void dma_dword64(uint32_t m0v, const void* base, uint32_t byte_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(byte_off), "s"(base) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_ubyte64(uint32_t m0v, const void* base, uint32_t byte_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2" ::"s"(m0v), "v"(byte_off), "s"(base) : "memory", "m0");
+}
+// wait until at most n of this wave's vector-memory operations are outstanding (n in {0, 4, 5, 6, 8, 10, 12}: the immediates the
+// ring kernels need)
+__device__ __forceinline__ void dma_wait(int n) {
+    if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+// workgroup barrier that orders LDS traffic only
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void dma_wait_barrier(int n) {
+    dma_wait(n);
+    lds_only_barrier();
+}
+
 }  // namespace
