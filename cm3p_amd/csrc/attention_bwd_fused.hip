@@ -184,37 +184,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     const int l31 = lane & 31, g4 = lane >> 4, i16 = lane & 15;
     const int n_tiles = (S + 63) / 64;
 
-    // ---- the wave's 64 keys: K / V row fragments (B operands of the score products, AGPRs) and its part of the K image
-    bf16x8 kf[2][4], vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int krow_c = min(k0 + 32 * kb + l31, S - 1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kf[kb][s] = gload_frag8(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
-            vf[kb][s] = gload_frag8(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
-        }
-    }
-    {
-        const uint8_t* km = kmask ? kmask + sv.row0 : nullptr;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 8 * i + (lane >> 3), c = lane & 7;
-            const int krow = k0 + row, rc = min(krow, S - 1);
-            uint4 v = *reinterpret_cast<const uint4*>(kbase + (int64_t)rc * ld + c * 8);
-            const bool vis = krow < S && (km == nullptr || km[rc] != 0);
-            if (!vis) v = uint4{0u, 0u, 0u, 0u};  // a key no query may see: its dS column meets a zero row in the dQ product
-            *reinterpret_cast<uint4*>(smem + kFKimg + off_R(64 * wid + row, c)) = v;
-        }
-    }
-    f32x16 dk[2][2], dv[2][2];  // [d block][key block]
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;
-
     // ---- LDS-DMA of a tile: wave w brings rows 16 w .. 16 w + 15 of Q and of dO (four 1-KiB pieces: lane l's 16 bytes land at
     // piece + 16 l, i.e. row l >> 3, chunk slot l & 7, which must hold global chunk (l & 7) ^ swz(row)) and, waves 0 / 1, the
     // tile's two statistics rows (waves 2 / 3 repeat them: every wave issues the same number of vector-memory operations, which
@@ -252,6 +221,48 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         const uint32_t m0v = m0_stat + (uint32_t)slot * kFStage;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(dvs), "s"(stat_bh) : "memory", "m0");
     };
+
+    // tiles 0 .. 2 are requested before the wave's own K / V rows: the two round trips overlap
+    dma_addr(0);
+    dma_rows(0);
+    dma_stat(0);
+    dma_addr(1);
+    dma_rows(1);
+    dma_stat(1);
+    dma_addr(2);
+    dma_rows(2);
+    dma_stat(2);
+
+    // ---- the wave's 64 keys: K / V row fragments (B operands of the score products, AGPRs) and its part of the K image
+    bf16x8 kf[2][4], vf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow_c = min(k0 + 32 * kb + l31, S - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[kb][s] = gload_frag8(kbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+            vf[kb][s] = gload_frag8(vbase + (int64_t)krow_c * ld + 16 * s + 8 * hh);
+        }
+    }
+    {
+        const uint8_t* km = kmask ? kmask + sv.row0 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (lane >> 3), c = lane & 7;
+            const int krow = k0 + row, rc = min(krow, S - 1);
+            uint4 v = *reinterpret_cast<const uint4*>(kbase + (int64_t)rc * ld + c * 8);
+            const bool vis = krow < S && (km == nullptr || km[rc] != 0);
+            if (!vis) v = uint4{0u, 0u, 0u, 0u};  // a key no query may see: its dS column meets a zero row in the dQ product
+            *reinterpret_cast<uint4*>(smem + kFKimg + off_R(64 * wid + row, c)) = v;
+        }
+    }
+    f32x16 dk[2][2], dv[2][2];  // [d block][key block]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;
 
     // ---- per-lane LDS byte offsets; everything else is an immediate
     int oR[4], oTlo[2], oThi[2];
@@ -545,16 +556,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         step(I1{}, I0{}, WB{}, I0{}, WA{}, I4{}, I0{}, WA{}, I8{}, sB, dpB, sA, dpA, nullptr, nullptr, nst, no_hook);
     };
 
-    // prologue: tiles 0 .. 2 by DMA, fragments of (tile 0, qb0), scores of its first block
-    dma_addr(0);
-    dma_rows(0);
-    dma_stat(0);
-    dma_addr(1);
-    dma_rows(1);
-    dma_stat(1);
-    dma_addr(2);
-    dma_rows(2);
-    dma_stat(2);
+    // prologue: (tiles 0 .. 2 are in flight since the top of the kernel) fragments of (tile 0, qb0), scores of its first block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // all three (the counted wait of the loop assumes its steady-state issue order)
     lds_barrier();
     // K^T of the workgroup's 256 keys, the wave's d block: the A operands of all 16 k-steps of the dQ product stay in AGPRs (the
