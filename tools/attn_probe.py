@@ -13,11 +13,11 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B, S, 3, nh, 64, device="cuda", generator=g).to(torch.bfloat16)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-out, lse = K.attn_fwd(qkv, None, B, S, nh, W, 0.125)
+out, lse = K.attn_fwd(qkv, None, B, S, nh, W, 0.125, True)
 do = torch.randn(B * S, nh * 64, device="cuda", generator=g).to(torch.bfloat16)
 for _ in range(5):
     if which == "fwd":
-        K.attn_fwd(qkv, None, B, S, nh, W, 0.125)
+        K.attn_fwd(qkv, None, B, S, nh, W, 0.125, True)
     else:
-        K.attn_bwd(qkv, out, do, lse, None, B, S, nh, W, 0.125)
+        K.attn_bwd(qkv, out, do, lse, None, B, S, nh, W, 0.125, None, False, True)
 torch.cuda.synchronize()
