@@ -82,3 +82,29 @@ def test_pointer_arguments_on_different_gpus_are_refused():
     a.dev, b.dev = 0, 1
     with pytest.raises(_lib.Cm3pHipError, match="different GPUs"):
         _lib._launch("cm3p_cast_f32_bf16", (a, b, 16, _lib.stream()))
+
+
+def test_fused_attention_backward_rejects_bad_arguments_without_a_gpu(lib_path):
+    """Argument validation happens before any HIP call: NULL tensors, a window request, an undersized workspace or an unknown
+    stage mask return CM3P_ERR_INVALID (-1) instead of launching."""
+    from cm3p_amd import _lib
+
+    lib = _lib.load()
+    need = lib.cm3p_attn_bwd_fused_workspace_bytes(2, 512, 4)
+    assert need == 2 * 4 * ((8 + 12) * 512 + 2 * (512 + 64) * 128)
+    fake = 4096  # an aligned, never dereferenced address: every call below must fail validation first
+    args = dict(qkv=fake, out=fake, dout=fake, lse=fake, dqkv=fake, key_mask=None, cu=None, B=2, S=512, total=0, nh=4, scale=0.125, cos=None, sin=None,
+                pbs=0, stages=7, pre=1, ws=fake, ws_bytes=need, stream=None)
+
+    def call(**kw):
+        a = dict(args, **kw)
+        return lib.cm3p_attn_bwd_fused(a["qkv"], a["out"], a["dout"], a["lse"], a["dqkv"], a["key_mask"], a["cu"], a["B"], a["S"], a["total"], a["nh"],
+                                       a["scale"], a["cos"], a["sin"], a["pbs"], a["stages"], a["pre"], a["ws"], a["ws_bytes"], a["stream"])
+
+    assert call(qkv=None) == -1
+    assert call(ws=None) == -1
+    assert call(ws_bytes=need - 1) == -1
+    assert call(stages=0) == -1 and call(stages=8) == -1
+    assert call(cos=fake, sin=None) == -1
+    assert call(cu=fake, total=0) == -1  # packed rows need their total
+    assert call(qkv=fake + 2) == -1  # 16-byte alignment
