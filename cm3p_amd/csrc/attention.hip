@@ -383,39 +383,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         if (t + 3 <= t_hi) dma_tile(t + 3);
         const int key0 = t * 64;
         if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
-            f32x16 sacc[2], dp[2];
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                // row constants as initial accumulators (log2 p, and dP - delta): the first MFMA of each chain reads them
-                // from two vectors that stay resident for the whole key sweep (the MFMA's C and D may differ), so no
-                // per-tile register fills are needed
-                sacc[blk] = mfma32(frag_R(st, 32 * blk, 0, lane), qf[0], lse_init);
-                dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, 0, lane), dof[0], dlt_init);
-#pragma unroll
-                for (int s = 1; s < 4; ++s) {
-                    sacc[blk] = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc[blk]);
-                    dp[blk] = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp[blk]);
-                }
-            }
             const uint32_t* mb = reinterpret_cast<const uint32_t*>(st + 16384);
             int all_valid = key0 + 63 < S;
             if constexpr (MASK) all_valid = all_valid && __all(mb[lane] != 0u);
-            if (!tile_unmasked(all_valid, key0, q0, window)) {
-                mask_scores_keyrows_d<MASK>(sacc[0], mb, 0, key0, lo, hi, hh);
-                mask_scores_keyrows_d<MASK>(sacc[1], mb, 1, key0, lo, hi, hh);
-            }
+            const bool unmasked = tile_unmasked(all_valid, key0, q0, window);
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
+            for (int blk = 0; blk < 2; ++blk) {
+                // (a 64-key tile that touches the wave's band may still hold a 32-key block that lies outside it: a quarter of the
+                //  blocks of a +-64 window)
+                if (key0 + 32 * blk > whi || key0 + 32 * blk + 31 < wlo) continue;
+                // row constants as initial accumulators (log2 p, and dP - delta): the first MFMA of each chain reads them
+                // from two vectors that stay resident for the whole key sweep (the MFMA's C and D may differ), so no
+                // per-tile register fills are needed
+                f32x16 sacc = mfma32(frag_R(st, 32 * blk, 0, lane), qf[0], lse_init);
+                f32x16 dp = mfma32(frag_R(st + 8192, 32 * blk, 0, lane), dof[0], dlt_init);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) {
+                    sacc = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc);
+                    dp = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp);
+                }
+                if (!unmasked) mask_scores_keyrows_d<MASK>(sacc, mb, blk, key0, lo, hi, hh);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(PRE ? sacc[blk][i] : sacc[blk][i] * c);
-                    sacc[blk][i] = p * dp[blk][i];  // dS^T / scale (the scale is applied once, to dQ)
+                    const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
+                    sacc[i] = p * dp[i];  // dS^T / scale (the scale is applied once, to dQ)
                 }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 dsf = acc_to_frag(sacc[s >> 1], s & 1);
-                dq[0] = mfma32(frag_T(st, 16 * s, 0, lane), dsf, dq[0]);  // K^T from the same image as the row reads
-                dq[1] = mfma32(frag_T(st, 16 * s, 1, lane), dsf, dq[1]);
+                for (int sp = 0; sp < 2; ++sp) {
+                    const bf16x8 dsf = acc_to_frag(sacc, sp);
+                    dq[0] = mfma32(frag_T(st, 32 * blk + 16 * sp, 0, lane), dsf, dq[0]);  // K^T from the same image as the row reads
+                    dq[1] = mfma32(frag_T(st, 32 * blk + 16 * sp, 1, lane), dsf, dq[1]);
+                }
             }
         }
     }
@@ -543,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
             const float* ndlt = nlse + 64;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {  // two 32-query blocks of the tile
+                // (a 64-row tile that touches the wave's band may still hold a 32-row block that lies outside it: a quarter of the
+                //  blocks of a +-64 window)
+                if (qt0 + 32 * qb > whi || qt0 + 32 * qb + 31 < wlo) continue;
                 f32x16 sacc, dp;
                 // initial accumulators: row constants -lse*log2(e) and -delta (rows = queries)
 #pragma unroll
