@@ -367,6 +367,21 @@ def test_attention_global_backward_both_implementations(K, monkeypatch, impl, S,
     _attn_case(K, 2 if lens is None else 3, S, 2, -1, lens, 21, prescaled=prescaled)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_attention_random_shapes(K, seed):
+    """Seeded sweep over odd shapes: lengths that are not multiples of the 32 / 64 / 256-row blocks, single-row sequences, ragged
+    padding (including an almost empty row), one to three heads, global and sliding-window layers, both q modes."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    S = int(torch.randint(1, 700, (1,), generator=g))
+    B = int(torch.randint(1, 4, (1,), generator=g))
+    nh = int(torch.randint(1, 4, (1,), generator=g))
+    window = -1 if seed % 2 == 0 else 64
+    lens = None
+    if seed % 3 != 0:
+        lens = [S] + [int(torch.randint(1, S + 1, (1,), generator=g)) for _ in range(B - 1)]
+    _attn_case(K, B, S, nh, window, lens, 2000 + seed, prescaled=seed % 4 < 2)
+
+
 def test_attention_fused_backward_matches_pair_and_is_deterministic(K, monkeypatch):
     B, S, nh = 3, 1100, 3
     g = torch.Generator().manual_seed(5)
