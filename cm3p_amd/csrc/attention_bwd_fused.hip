@@ -14,13 +14,17 @@
 //           is kept (attention_bwd.hip); new here:
 //             - tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write; swizzled by permuting the
 //               SOURCE chunks since the DMA writes lane-linearly), three slots, a tile's DMA is in flight for two tile periods;
-//               ordering is explicit: a counted s_waitcnt vmcnt in front of the single workgroup barrier per tile;
+//               ordering is explicit: a counted s_waitcnt vmcnt in front of the single workgroup barrier per tile (every wave
+//               issues exactly five DMAs and two stores per tile, DMAs first: tests/test_kernel_isa.py pins the pattern);
 //             - dS leaves the accumulator layout (key on the lane) through a [256 keys][64 queries] bf16 image in LDS, two
 //               images, each holding a half-shifted 64-query window ("epoch": second half of tile t-1, first half of tile t) so
 //               that the ONE barrier per tile (between steps 1 and 2) both publishes an epoch and retires the one before;
 //             - dQ^T of an epoch = K^T dS^T over the workgroup's 256 keys, 16 MFMAs per wave (wave w owns d block w >> 1, query
-//               block w & 1), four per pipeline step, operands by transposed reads of the K image (invisible keys are stored as
-//               ZERO rows: nothing is masked in the loop) and of the dS image; the bf16 partial goes to this key block's slab;
+//               block w & 1), four per pipeline step.  K^T comes from a K image (transposed reads; invisible keys are stored as
+//               ZERO rows: nothing is masked in the loop) ONCE: 15 of its 16 fragments stay in AGPRs for the whole kernel (a wave
+//               keeps at most 15 LDS operations in flight, so LDS instruction count is a throughput limit at one wave per
+//               SIMD); dS^T by transposed reads of the dS image.  The finished bf16 block goes through a wave-private
+//               transposition buffer to this key block's slab as whole 64-byte row pieces (16 rows per store instruction);
 //             - exponentials carry the hardware clamp (v_exp_f32 ... clamp): p <= 1 also for keys under the padding mask, whose
 //               scores the row maximum does not bound, so dS stays finite and meets the zero K row as an exact zero.
 //   reduce  dq = scale * inverse_rope(sum of the key blocks' bf16 slabs, fp32, fixed order) -> the q third of dqkv.
