@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 
 // ---------------------------------------------------------------------------------------------------------------
 // dQ (and delta[b, h, q] = sum_d dO[q, d] * O[q, d], which it computes for its own rows and publishes for the dK/dV kernel):
-// same geometry as the forward.  LDS per stage: K image (row + transposed reads) + V image + mask bytes.
+// same geometry as the forward.  LDS per ring slot: K image (row + transposed reads) + V image + one validity dword per key; tiles
+// arrive by LDS-DMA (TileDma, attn_common.h), the result leaves as whole rows (store_rows32).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDqStage = 2 * 8192 + 256;  // K image, V image, one validity dword per key
 constexpr int kDqSlots = 4;               // LDS-DMA ring: tile t+3 is requested while tile t is consumed
@@ -435,7 +436,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // ---------------------------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = 4 waves = 128 keys of one (batch, head); each wave owns 32 keys (key on the lane) and keeps
 // dK^T, dV^T (64 x 32 each) in accumulators while the workgroup sweeps query tiles of 64 rows.
-// LDS per stage: Q image + dO image (8 KiB each, row and transposed reads) + -lse*log2(e) and -delta (64 floats each).
+// LDS per ring slot: Q image + dO image (8 KiB each, row and transposed reads) + the rows' lse and delta (raw, 64 floats each:
+// the accumulator init multiplies / negates them); tiles arrive by LDS-DMA, dK / dV leave as whole rows (store_rows32).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, the rows' lse and delta (raw, 64 floats each)
 constexpr int kDkvSlots = 4;               // LDS-DMA ring, as in the dq kernel
