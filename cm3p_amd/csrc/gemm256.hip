@@ -27,6 +27,9 @@ constexpr int kWN = CM3P_G256_WN;
 constexpr int kThreads = 128 * kWN;      // 512 or 256
 constexpr int kNJ = 16 / kWN;            // 16-column MFMA tiles per wave: 4 or 8
 constexpr int kWaveN = TN / kWN;         // 64 or 128
+#ifndef CM3P_G256_ABL
+#define CM3P_G256_ABL 0  // timing-only probes (results invalid): 1 no LDS-DMA of the B operand in the steady state, 2 no B fragment reads
+#endif
 constexpr int kPieces = 16 / kWN;        // 1-KiB LDS-DMA pieces per wave, operand and k-tile: 4 or 8
 constexpr int kItems = 2048 / kThreads;  // 16-byte store items per thread and epilogue pass: 4 or 8
 constexpr int kOperandBytes = TM * TK * 2;  // 32 KiB
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
             auto issue_at = [&](int g) {
                 if (steady && g == ((A_KC && kWN == 4 && wm == 1) ? 0 : -1)) {
                     sa.issue(nxt, wid);
-                    sb.issue(nxt + kOperandBytes, wid);
+                    if constexpr (!(CM3P_G256_ABL & 1)) sb.issue(nxt + kOperandBytes, wid);
                 }
             };
             if (!steady && has_next) {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
                     const int kk = g >> 1, half = g & 1;
                     if (g < 3) {
                         const int kn = (g + 1) >> 1, hn = (g + 1) & 1;
-                        if (hn == 0) {
+                        if (hn == 0 && !(CM3P_G256_ABL & 2)) {
 #pragma unroll
                             for (int j = 0; j < kNJ; ++j) fbq[kn & 1][j] = frag<B_KC>(ib, wn * kWaveN + j * 16, kn, lane);
                         }
