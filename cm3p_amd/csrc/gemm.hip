@@ -266,6 +266,27 @@ int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R,
                           int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
                           int64_t c_split_stride, hipStream_t s, RopeArgs rope);
 
+// gemm8p.hip: the same tile on the half-tile ring ("8-phase" schedule); CM3P_ERR_INVALID = shape / layout not covered
+int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                         int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
+                         int64_t c_split_stride, hipStream_t s, RopeArgs rope);
+
+// Development switch (read per call so that one process can A/B): CM3P_GEMM_IMPL=256 keeps the r01 kernel for every big shape.
+static inline bool use_8p() {
+    const char* e = getenv("CM3P_GEMM_IMPL");
+    return !(e && e[0] == '2');
+}
+
+static inline int big_gemm(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s,
+                           RopeArgs rope) {
+    if (use_8p()) {
+        const int rc = cm3p_gemm8p_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, splits, kchunk, c_split_stride, s, rope);
+        if (rc != CM3P_ERR_INVALID) return rc;
+    }
+    return cm3p_gemm256_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, splits, kchunk, c_split_stride, s, rope);
+}
+
 static inline int64_t tiles_of(int64_t M, int64_t N, int t) { return ((M + t - 1) / t) * ((N + t - 1) / t); }
 
 extern "C" {
@@ -298,7 +319,7 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
     // (the 256 x 256 kernel decides per tile whether its columns are rotated: the rotated range must end on a tile boundary)
     const bool big = (K % 64 == 0) && (rope_cols % 256 == 0) && M < (int64_t(1) << 31) && tiles_of(M, N, 256) >= 200;
     int rc;
-    if (big) rc = cm3p_gemm256_dispatch(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, 1, 1, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
+    if (big) rc = big_gemm(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, 1, 1, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
     else rc = launch<true, true>(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
@@ -330,7 +351,7 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
     }
     int rc;
     const bool big = (K % 64 == 0) && (kchunk % 64 == 0) && tiles_of(M, N, 256) * split_k >= 200;
-    if (big) rc = cm3p_gemm256_dispatch(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s, RopeArgs{});
+    if (big) rc = big_gemm(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s, RopeArgs{});
     else if (a_kc && b_kc) rc = launch<true, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (a_kc) rc = launch<true, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (b_kc) rc = launch<false, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);

@@ -52,6 +52,17 @@ def main():
             print(f"gemm dgrad {name:5s} [{T}x{Kd}x{N}] {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s")
             ms = timeit(lambda: K.linear_wgrad(dy, a), args.iters)
             print(f"gemm wgrad {name:5s} [{N}x{Kd}x{T}] {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s")
+    if "cube" in args.what:
+        # square shapes on uniform random [-1, 1) operands: comparable with the guide's 256^2 8-phase template numbers
+        # (cdna_hip_programming.md "The 256^2 8-phase template": 1.32-1.34 PF at 4096^3, 1.47 PF at 8192^3)
+        for n in (4096, 8192):
+            a = (torch.rand(n, n, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+            b = (torch.rand(n, n, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+            fl = 2.0 * n ** 3
+            for name, fn in (("fwd  (kc,kc)", lambda: K.linear_fwd(a, b)), ("dgrad(kc,ks)", lambda: K.linear_dgrad(a, b)),
+                             ("wgrad(ks,ks)", lambda: K.linear_wgrad(a, b))):
+                ms = min(timeit(fn, args.iters) for _ in range(3))
+                print(f"cube {n}^3 {name} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF/s", flush=True)
     if "attn" in args.what:
         qkv = rnd(B, S, 3, nh, 64)
         do = rnd(T, nh * 64)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""One-process A/B of the two big-shape GEMM kernels (CM3P_GEMM_IMPL=256: gemm256.hip, default: gemm8p.hip): results compared
+element by element (same accumulation order: bit-identical expected), then interleaved timing rounds (median and min).
+
+    python tools/gemm_ab.py [--rounds 5] [--iters 20] [check] [cube] [step]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cm3p_amd import kernels as K  # noqa: E402
+from tools.bench_kernels import timeit  # noqa: E402
+
+DEV = "cuda"
+
+
+def impl(name):
+    os.environ["CM3P_GEMM_IMPL"] = name
+
+
+def ab(label, fn, flops, rounds, iters):
+    res = {"256": [], "8p": []}
+    for _ in range(rounds):
+        for name in ("256", "8p"):
+            impl(name)
+            res[name].append(timeit(fn, iters))
+    a, b = res["256"], res["8p"]
+    print(f"{label:34s} 256: {statistics.median(a):7.3f} ms (min {min(a):7.3f}) {flops / statistics.median(a) / 1e9:7.1f} TF/s | "
+          f"8p: {statistics.median(b):7.3f} ms (min {min(b):7.3f}) {flops / statistics.median(b) / 1e9:7.1f} TF/s | x{statistics.median(a) / statistics.median(b):.3f}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["check", "cube", "step"])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    uni = lambda *s: (torch.rand(*s, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
+
+    if "check" in args.what:
+        bad = 0
+        for (M, N, Kd) in ((4096, 4096, 4096), (131072, 2304, 768), (65536, 768, 1152), (65536 + 64, 1152, 768), (8192 + 8, 2304 + 64, 64),
+                           (12800, 768, 192), (256 * 30, 256 * 7, 128)):
+            a, w = uni(M, Kd), uni(N, Kd)
+            r = torch.randn(M, N, device=DEV, generator=g)
+            outs = {}
+            for name in ("256", "8p"):
+                impl(name)
+                outs[name] = (K.linear_fwd(a, w), K.linear_fwd(a, w, resid=r), K.gemm(a, w, M, N, Kd, True, True, K.EPI_F32))
+            torch.cuda.synchronize()
+            for i, kind in enumerate(("bf16", "f32+resid", "f32")):
+                x, y = outs["256"][i].float(), outs["8p"][i].float()
+                d = (x - y).abs().max().item()
+                ref = (a[:64].float() @ w.float().T) + (r[:64] if i == 1 else 0)
+                dr = (y[:64] - ref).abs().max().item()
+                ok = d == 0.0
+                bad += (not ok)
+                print(f"check [{M}x{N}x{Kd}] {kind:9s} max|256-8p| = {d:.3e}  max|8p-torch| (64 rows) = {dr:.3e}  {'OK' if ok else 'MISMATCH'}", flush=True)
+        if bad:
+            print(f"{bad} MISMATCHES")
+            sys.exit(1)
+    if "cube" in args.what:
+        for n in (4096, 8192):
+            a, b = uni(n, n), uni(n, n)
+            ab(f"cube {n}^3 fwd bf16", lambda: K.linear_fwd(a, b), 2.0 * n ** 3, args.rounds, args.iters)
+    if "step" in args.what:
+        T, H, I = 131072, 768, 1152
+        x, g1 = rnd(T, H), rnd(T, I)
+        for name, N, Kd, a in (("Wqkv/Wi", 3 * H, H, x), ("Wo", H, H, x), ("Wo2", H, I, g1)):
+            w = rnd(N, Kd) * 0.02
+            r = torch.randn(T, N, device=DEV, generator=g) if N == H else None
+            ab(f"fwd {name} [{T}x{N}x{Kd}]" + (" +resid" if r is not None else ""), lambda: K.linear_fwd(a, w, resid=r), 2.0 * T * N * Kd, args.rounds, args.iters)
+            if r is not None:
+                ab(f"fwd {name} [{T}x{N}x{Kd}] bf16", lambda: K.linear_fwd(a, w), 2.0 * T * N * Kd, args.rounds, args.iters)
+        cos = torch.randn(4096, 32, device=DEV, generator=g)
+        sin = torch.randn(4096, 32, device=DEV, generator=g)
+        w = rnd(3 * H, H) * 0.02
+        ab("fwd Wqkv+rope", lambda: K.qkv_linear_rope(x, w, cos, sin, 4096, False, K.SOFTMAX_Q_SCALE), 2.0 * T * 3 * H * H, args.rounds, args.iters)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+// Stand-alone harness for the big-shape GEMM kernels (no torch): links libcm3p_hip.so, runs cm3p_gemm_bf16 with CM3P_GEMM_IMPL=256
+// and the default (gemm8p.hip) on the same operands, compares every element, checks guard zones around the output, then times both
+// in interleaved rounds.  Every buffer sits in the middle of one large allocation with 64 MiB of owned memory on both sides, so a
+// near out-of-bounds access corrupts a guard (reported) instead of faulting the GPU.
+//   hipcc -O2 -o /tmp/gemm_harness tools/ubench/gemm_harness.cpp -Lcm3p_amd/csrc -lcm3p_hip -Wl,-rpath,$PWD/cm3p_amd/csrc
+//   /tmp/gemm_harness [check] [time]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/cm3p_hip.h"
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                           \
+        }                                                                      \
+    } while (0)
+
+static const size_t GUARD = 64u << 20;
+
+__global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float v = ((h & 0xffffff) / 8388608.0f - 1.0f) * scale;
+        p[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+}
+__global__ void fill_f32(float* p, size_t n, uint32_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h & 0xffffff) / 8388608.0f - 1.0f;
+    }
+}
+__global__ void fill_u32(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void count_neq_u32(const uint32_t* p, size_t n, uint32_t v, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += p[i] != v;
+    if (c) atomicAdd(out, c);
+}
+__global__ void count_diff_u32(const uint32_t* a, const uint32_t* b, size_t n, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
+}
+
+struct Guarded {
+    char* base = nullptr;
+    size_t bytes = 0;
+    char* p() const { return base + GUARD; }
+    void alloc(size_t n) {
+        bytes = (n + 255) & ~size_t(255);
+        CK(hipMalloc(&base, bytes + 2 * GUARD));
+        fill_u32<<<1024, 256>>>((uint32_t*)base, (bytes + 2 * GUARD) / 4, 0xDEADBEEFu);
+    }
+    unsigned long long guards_touched(unsigned long long* d_cnt) const {
+        CK(hipMemset(d_cnt, 0, 8));
+        count_neq_u32<<<1024, 256>>>((const uint32_t*)base, GUARD / 4, 0xDEADBEEFu, d_cnt);
+        count_neq_u32<<<1024, 256>>>((const uint32_t*)(base + GUARD + bytes), GUARD / 4, 0xDEADBEEFu, d_cnt);
+        unsigned long long h;
+        CK(hipMemcpy(&h, d_cnt, 8, hipMemcpyDeviceToHost));
+        return h;
+    }
+    void release() { CK(hipFree(base)); }
+};
+
+static void impl(const char* s) { setenv("CM3P_GEMM_IMPL", s, 1); }
+
+int main(int argc, char** argv) {
+    bool do_check = argc < 2, do_time = argc < 2;
+    for (int i = 1; i < argc; ++i) {
+        do_check |= !strcmp(argv[i], "check");
+        do_time |= !strcmp(argv[i], "time");
+    }
+    unsigned long long* d_cnt;
+    CK(hipMalloc(&d_cnt, 8));
+    struct Shape { int64_t M, N, K; };
+    const Shape shapes[] = {{4096, 4096, 4096}, {131072, 2304, 768}, {65536, 768, 1152}, {65536 + 64, 1152, 768}, {8192 + 8, 2304 + 64, 64}, {256 * 30, 256 * 7, 128}};
+    const int epis[] = {CM3P_EPI_BF16, CM3P_EPI_F32_RESID, CM3P_EPI_F32};
+    const char* epi_names[] = {"bf16", "f32+resid", "f32"};
+    int bad = 0;
+    if (do_check) {
+        for (const Shape& s : shapes) {
+            Guarded A, B, R, C0, C1;
+            A.alloc(s.M * s.K * 2);
+            B.alloc(s.N * s.K * 2);
+            R.alloc(s.M * s.N * 4);
+            C0.alloc(s.M * s.N * 4);
+            C1.alloc(s.M * s.N * 4);
+            fill_bf16<<<1024, 256>>>((uint16_t*)A.p(), s.M * s.K, 1u, 1.f);
+            fill_bf16<<<1024, 256>>>((uint16_t*)B.p(), s.N * s.K, 2u, 1.f);
+            fill_f32<<<1024, 256>>>((float*)R.p(), s.M * s.N, 3u);
+            CK(hipDeviceSynchronize());
+            for (int e = 0; e < 3; ++e) {
+                const size_t out_bytes = s.M * s.N * (epis[e] == CM3P_EPI_BF16 ? 2 : 4);
+                printf("check [%ld x %ld x %ld] %-9s ... ", (long)s.M, (long)s.N, (long)s.K, epi_names[e]);
+                fflush(stdout);
+                impl("256");
+                int rc0 = cm3p_gemm_bf16(A.p(), B.p(), C0.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, s.K, s.K, s.N, 1, 1, epis[e], 1, nullptr, nullptr);
+                CK(hipDeviceSynchronize());
+                printf("256 rc=%d ", rc0);
+                fflush(stdout);
+                impl("8p");
+                int rc1 = cm3p_gemm_bf16(A.p(), B.p(), C1.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, s.K, s.K, s.N, 1, 1, epis[e], 1, nullptr, nullptr);
+                CK(hipDeviceSynchronize());
+                printf("8p rc=%d ", rc1);
+                fflush(stdout);
+                CK(hipMemset(d_cnt, 0, 8));
+                count_diff_u32<<<1024, 256>>>((const uint32_t*)C0.p(), (const uint32_t*)C1.p(), out_bytes / 4, d_cnt);
+                unsigned long long nd;
+                CK(hipMemcpy(&nd, d_cnt, 8, hipMemcpyDeviceToHost));
+                const unsigned long long g = C1.guards_touched(d_cnt);
+                printf("differing dwords %llu / %zu, guard dwords touched %llu  %s\n", nd, out_bytes / 4, g, (nd || g || rc0 || rc1) ? "FAIL" : "OK");
+                fflush(stdout);
+                bad += (nd || g || rc0 || rc1) ? 1 : 0;
+                // restore the part of C1 beyond out_bytes? (none: outputs are fully overwritten each time)
+            }
+            A.release(); B.release(); R.release(); C0.release(); C1.release();
+        }
+        printf("%d failing cases\n", bad);
+    }
+    if (do_time) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        struct T { int64_t M, N, K; int epi; const char* name; };
+        const T ts[] = {{4096, 4096, 4096, CM3P_EPI_BF16, "cube 4096 bf16"}, {8192, 8192, 8192, CM3P_EPI_BF16, "cube 8192 bf16"},
+                        {131072, 2304, 768, CM3P_EPI_BF16, "Wqkv/Wi fwd bf16"}, {131072, 768, 768, CM3P_EPI_F32_RESID, "Wo fwd f32+resid"},
+                        {131072, 768, 768, CM3P_EPI_BF16, "Wo-shape bf16"}, {131072, 768, 1152, CM3P_EPI_F32_RESID, "Wo2 fwd f32+resid"},
+                        {131072, 768, 2304, CM3P_EPI_BF16, "dgrad-shape K=2304 bf16 (kc,kc)"}};
+        for (const T& t : ts) {
+            Guarded A, B, R, C;
+            A.alloc(t.M * t.K * 2); B.alloc(t.N * t.K * 2); R.alloc(t.M * t.N * 4); C.alloc(t.M * t.N * 4);
+            fill_bf16<<<1024, 256>>>((uint16_t*)A.p(), t.M * t.K, 1u, 1.f);
+            fill_bf16<<<1024, 256>>>((uint16_t*)B.p(), t.N * t.K, 2u, 1.f);
+            fill_f32<<<1024, 256>>>((float*)R.p(), t.M * t.N, 3u);
+            CK(hipDeviceSynchronize());
+            std::vector<float> ms[2];
+            for (int round = 0; round < 5; ++round)
+                for (int which = 0; which < 2; ++which) {
+                    impl(which ? "8p" : "256");
+                    const float* r = t.epi == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr;
+                    for (int i = 0; i < 3; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.K, t.K, t.N, 1, 1, t.epi, 1, nullptr, nullptr);
+                    CK(hipEventRecord(e0));
+                    const int iters = 20;
+                    for (int i = 0; i < iters; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.K, t.K, t.N, 1, 1, t.epi, 1, nullptr, nullptr);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float m;
+                    CK(hipEventElapsedTime(&m, e0, e1));
+                    ms[which].push_back(m / iters);
+                }
+            for (auto& v : ms) std::sort(v.begin(), v.end());
+            const double fl = 2.0 * t.M * t.N * t.K;
+            printf("%-34s 256: %7.3f ms (min %7.3f) %7.1f TF/s | 8p: %7.3f ms (min %7.3f) %7.1f TF/s | x%.3f\n", t.name, ms[0][2], ms[0][0],
+                   fl / ms[0][2] / 1e9, ms[1][2], ms[1][0], fl / ms[1][2] / 1e9, ms[0][2] / ms[1][2]);
+            fflush(stdout);
+            A.release(); B.release(); R.release(); C.release();
+        }
+    }
+    return bad ? 1 : 0;
+}
