@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -34,6 +34,7 @@ SIGNATURES = {
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],
     "cm3p_gemm_wgrad_splits": [_L, _L, _L],
+    "cm3p_build_ablation_flags": [],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
     "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
@@ -108,6 +109,10 @@ def load() -> ctypes.CDLL:
         fn.restype = c_int64 if name in _RETURNS_INT64 else c_int
     if lib.cm3p_abi_version() != ABI_VERSION:
         raise Cm3pHipError(f"ABI mismatch: library {lib.cm3p_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    if lib.cm3p_build_ablation_flags() != 0 and os.environ.get("CM3P_ALLOW_ABLATED_LIB") != "1":
+        raise Cm3pHipError(
+            f"{LIB_PATH} was built with timing-only ablation macros (mask {lib.cm3p_build_ablation_flags():#x}): its results are wrong by "
+            "construction.  Rebuild with `python -m cm3p_amd.build --force`; kernel-timing scripts set CM3P_ALLOW_ABLATED_LIB=1.")
     _lib = lib
     return lib
 

@@ -743,3 +743,6 @@ int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, con
 }
 
 }  // extern "C"
+
+// timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
+int cm3p_ablation_flags_attention() { return (CM3P_BABL); }

@@ -759,3 +759,6 @@ int cm3p_launch_attn_bwd_global(const void* qkv, const void* out, const void* do
     }
     return CM3P_OK;
 }
+
+// timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
+int cm3p_ablation_flags_attention_bwd() { return (CM3P_ABL); }

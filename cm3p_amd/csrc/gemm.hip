@@ -289,7 +289,18 @@ static inline int big_gemm(const void* A, const void* B, void* C, const float* R
 
 static inline int64_t tiles_of(int64_t M, int64_t N, int t) { return ((M + t - 1) / t) * ((N + t - 1) / t); }
 
+int cm3p_ablation_flags_attention();
+int cm3p_ablation_flags_attention_bwd();
+int cm3p_ablation_flags_attention_bwd_fused();
+int cm3p_ablation_flags_gemm256();
+int cm3p_ablation_flags_gemm8p();
+
 extern "C" {
+
+int cm3p_build_ablation_flags(void) {
+    return (cm3p_ablation_flags_attention() != 0) | (cm3p_ablation_flags_attention_bwd() != 0) << 1 | (cm3p_ablation_flags_attention_bwd_fused() != 0) << 2 |
+           (cm3p_ablation_flags_gemm256() != 0) << 3 | (cm3p_ablation_flags_gemm8p() != 0) << 4;
+}
 
 int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {
     // dW = dy^T x: few output tiles, contraction over all tokens.  Aim at ~2 workgroups per CU.

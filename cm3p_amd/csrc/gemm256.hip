@@ -452,3 +452,6 @@ int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R,
     if (b_kc) return launch256<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
     return launch256<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
 }
+
+// timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
+int cm3p_ablation_flags_gemm256() { return (CM3P_G256_ABL) | ((CM3P_G256_WN != 4) << 8); }

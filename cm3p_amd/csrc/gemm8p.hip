@@ -28,6 +28,11 @@
 
 #include "common.h"
 
+#ifndef CM3P_G8P_ABL
+#define CM3P_G8P_ABL 0  // timing-only probes (results invalid; tools/ubench/gemm8p_ablate.sh): 1 no global stores / residual loads in the
+                        // epilogue, 2 no epilogue at all, 4 accumulators not zeroed, 8 no counted vmcnt wait in phase 4
+#endif
+
 namespace {
 
 constexpr int kHalf = 16384;                 // one half-tile
@@ -44,16 +49,99 @@ __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_
                  : "memory", "m0", "scc");
 }
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // (HIP's uint4 is a struct: arrays of it land in scratch)
+
+#if CM3P_G8P_ABL & 1
+#define G8P_GLOBAL(stmt) asm volatile("" ::: "memory")
+#else
+#define G8P_GLOBAL(stmt) stmt
+#endif
 #define G8P_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define G8P_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int EPI>
+// One GEMM operand (A: rows of the output tile, B: its columns) as the staging stream and the fragment reader see it.
+//   KC  k-contiguous: element (idx, k) at X[idx * ld + k].  Half-tile image [128 idx][64 k], 128-byte rows, 16-byte chunk ^ (idx & 7).
+//   !KC k-strided:    element (idx, k) at X[k * ld + idx].  Half-tile image [64 k][128 idx], 256-byte rows, 32-byte segment index
+//       XOR f(k), f(k) = (k & 3) | ((k >> 3) & 1) << 2, read with ds_read_b64_tr_b16 (the layout rule of gemm256.hip at half width).
+// Which 128 of the tile's 256 idx a half-tile holds: position j of half h is tile idx (j / G) * 2G + h * G + j % G with G = 64 (A) or
+// 32 (B), so that wave row wr / wave column wc owns a contiguous 128 x 64 block of the output.
+template <bool KC, bool IS_A>
+struct Operand {
+    static constexpr int G = IS_A ? 64 : 32;
+    const char* p[2][2];  // [half][piece]: wave-uniform source base of this wave's two 1-KiB pieces (KS: the same for both halves)
+    uint32_t voff[2];     // [half]: per-lane byte offset added to the base (KC: the same for both halves)
+    int64_t kstep;        // bytes from one k-tile to the next
+    int fbase;            // per-lane LDS offset of the fragment reads
+
+    __device__ __forceinline__ void init(int64_t ld, int wid, int lane) {
+        const int wx = IS_A ? (wid >> 2) : (wid & 3);
+        if constexpr (KC) {
+            kstep = 128;
+            voff[0] = voff[1] = (uint32_t)((lane >> 3) * (int)ld * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
+            fbase = (wx * G + (lane & 15)) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
+        } else {
+            kstep = 128 * ld;
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            fbase = (8 * g + q) * 256 + 8 * pp + (((wx * (G / 16)) ^ (q | ((g & 1) << 2))) << 5);
+        }
+    }
+    // item = (idx0, kbeg); KC: clamp whole 8-row pieces, KS: clamp each lane's 8 idx (extent % 8 == 0: a piece / a lane's 16 bytes
+    // is inside or outside as a whole; what is loaded for the outside is never stored)
+    __device__ __forceinline__ void setup(const uint16_t* X, int64_t ld, int64_t idx0, int64_t extent, int64_t kbeg, int wid, int lane) {
+        if constexpr (KC) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int j = 16 * wid + 8 * i;
+                    int64_t idx = idx0 + (j / G) * 2 * G + h * G + j % G;
+                    if (idx > extent - 8) idx = extent - 8;
+                    p[h][i] = reinterpret_cast<const char*>(X + idx * ld + kbeg);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) p[0][i] = p[1][i] = reinterpret_cast<const char*>(X + (kbeg + 8 * wid + 4 * i) * ld + idx0);
+            // lane l brings LDS bytes [16 l, 16 l + 16) of the piece: k row l >> 4, 16-byte chunk c = l & 15 = (segment' << 1) | half
+            const int kl = lane >> 4, c = lane & 15;
+            const int seg = (c >> 1) ^ (kl | ((wid & 1) << 2));  // f(k) for k = 8 wid + 4 i + kl
+            const int j = seg * 16 + (c & 1) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int64_t idx = idx0 + (j / G) * 2 * G + h * G + j % G;
+                if (idx > extent - 8) idx = extent - 8;
+                voff[h] = (uint32_t)(kl * (int)ld * 2 + (int)(idx - idx0) * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) p[h][i] += kstep;
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void stage(int h, uint32_t lds) const {
+        glds_s<SLOT>(voff[h], p[h][0], lds);
+        glds_s<SLOT + 1024>(voff[h], p[h][1], lds);
+    }
+    // fragment t (16 idx) of this wave's share of a half-tile, k sub-step kk (32 deep); `off` = parity offset + slot offset
+    __device__ __forceinline__ bf16x8 frag(const char* smem, int off, int t, int kk) const {
+        if constexpr (KC) {
+            return *reinterpret_cast<const bf16x8*>(smem + (fbase ^ (kk ? 64 : 0)) + off + t * 2048);
+        } else {
+            const char* a = smem + (fbase ^ (t << 5)) + off + kk * 8192;
+            return cat_bf16x4(lds_read_tr16(a), lds_read_tr16(a + 1024));
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                         int64_t ldc, int tiles_n, int ntiles, int total, int64_t kchunk,
                                                         int64_t c_split_stride, RopeArgs rope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, lane_ = lane;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const uint32_t ldsw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem) + wid * 2048;
@@ -69,10 +157,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         n0 = (int64_t)(t % tiles_n) * 256;
     };
 
-    // ---- staging stream: scalar (wave-uniform) source bases of this wave's 8 pieces of one k-tile; lanes add a constant offset
-    const char* sa[2][2];  // [A-lo | A-hi][piece]
-    const char* sb[2][2];
-    const char* sah[2];    // A-hi one k-tile behind (it is staged in phase 1 of the following k-tile)
+    // ---- staging stream: runs two k-tiles ahead of the MFMAs and straight on into the next work item
+    Operand<A_KC, true> oa;
+    Operand<B_KC, false> ob;
+    oa.init(lda, wid, lane);
+    ob.init(ldb, wid, lane);
+    const char* sah[2];  // A-hi one k-tile behind (it is staged in phase 1 of the following k-tile)
+    uint32_t vah;
     int sv = blockIdx.x, skt = 0, snk = 0;
     bool sdone = false;  // the stream has passed this workgroup's last k-tile: the last k-tile is re-staged (never read; keeps the vmcnt pattern fixed)
     auto stream_setup = [&](int v) {
@@ -81,31 +172,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         decode(v, m0, n0, z);
         const int64_t kbeg = (int64_t)z * kchunk;
         snk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int64_t row = m0 + wr * 128 + h * 64 + wc * 16 + 8 * i;
-                if (row > M - 8) row = M - 8;  // rows past the edge are never stored (M % 8 == 0 on this path)
-                sa[h][i] = reinterpret_cast<const char*>(A + row * lda + kbeg);
-                int64_t col = n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + 8 * i;
-                if (col > N - 8) col = N - 8;
-                sb[h][i] = reinterpret_cast<const char*>(B + col * ldb + kbeg);
-            }
+        oa.setup(A, lda, m0, M, kbeg, wid, lane);
+        ob.setup(B, ldb, n0, N, kbeg, wid, lane);
     };
     auto stream_advance = [&]() {
-        sah[0] = sa[1][0];
-        sah[1] = sa[1][1];
+        sah[0] = oa.p[1][0];
+        sah[1] = oa.p[1][1];
+        vah = oa.voff[1];
         if (sdone) return;
         ++skt;
         if (skt < snk) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    sa[h][i] += 128;
-                    sb[h][i] += 128;
-                }
+            oa.advance();
+            ob.advance();
         } else {
             skt = 0;
             sv += gridDim.x;
@@ -113,145 +191,133 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
             else sdone = true;
         }
     };
-    const uint32_t voffa = (uint32_t)((lane >> 3) * (int)lda * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
-    const uint32_t voffb = (uint32_t)((lane >> 3) * (int)ldb * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
-
-    // ---- fragment addresses: LDS row r' = base row + (lane & 15), 16-byte chunk kk*4 + (lane >> 4), XOR (r' & 7)
-    const int xk0 = (((lane >> 4) ^ (lane & 7)) << 4);
-    const int fa_base = (wr * 64 + (lane & 15)) * 128 + xk0;  // kk = 1: the chunk index gains 4, i.e. the byte offset ^ 64
-    const int fb_base = (wc * 32 + (lane & 15)) * 128 + xk0;
-    // (one code path for both k-tile parities - the parity is a run-time 64 KiB offset: accumulators written in two branches
-    //  that merge are duplicated by the compiler and spilled)
-    auto frag_at = [&](int base, int off, int kk) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(smem + (base ^ (kk ? 64 : 0)) + off);
-    };
 
     f32x4 acc[8][4];
 
     // prologue: stream k-tiles 0 (all four halves) and 1 (B-lo, A-lo, B-hi); A-hi of k-tile 1 follows in phase 1 of k-tile 0
     stream_setup(sv);
-    glds_s<slot_off(0, kAL)>(voffa, sa[0][0], ldsw);
-    glds_s<slot_off(0, kAL) + 1024>(voffa, sa[0][1], ldsw);
-    glds_s<slot_off(0, kBL)>(voffb, sb[0][0], ldsw);
-    glds_s<slot_off(0, kBL) + 1024>(voffb, sb[0][1], ldsw);
-    glds_s<slot_off(0, kBH)>(voffb, sb[1][0], ldsw);
-    glds_s<slot_off(0, kBH) + 1024>(voffb, sb[1][1], ldsw);
-    glds_s<slot_off(0, kAH)>(voffa, sa[1][0], ldsw);
-    glds_s<slot_off(0, kAH) + 1024>(voffa, sa[1][1], ldsw);
+    oa.template stage<slot_off(0, kAL)>(0, ldsw);
+    ob.template stage<slot_off(0, kBL)>(0, ldsw);
+    ob.template stage<slot_off(0, kBH)>(1, ldsw);
+    oa.template stage<slot_off(0, kAH)>(1, ldsw);
     stream_advance();
-    glds_s<slot_off(1, kBL)>(voffb, sb[0][0], ldsw);
-    glds_s<slot_off(1, kBL) + 1024>(voffb, sb[0][1], ldsw);
-    glds_s<slot_off(1, kAL)>(voffa, sa[0][0], ldsw);
-    glds_s<slot_off(1, kAL) + 1024>(voffa, sa[0][1], ldsw);
-    glds_s<slot_off(1, kBH)>(voffb, sb[1][0], ldsw);
-    glds_s<slot_off(1, kBH) + 1024>(voffb, sb[1][1], ldsw);
+    ob.template stage<slot_off(1, kBL)>(0, ldsw);
+    oa.template stage<slot_off(1, kAL)>(0, ldsw);
+    ob.template stage<slot_off(1, kBH)>(1, ldsw);
     stream_advance();  // sah = A-hi of k-tile 1, state = k-tile 2
     G8P_WAIT_VM(6);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind
 
-    auto mma = [&](auto Ic, auto Jc, const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2]) {
+    // FIRST: the first k-tile of a work item starts its accumulators from the MFMA's zero operand instead of 128 v_mov per tile
+    auto mma = [&](auto Fc, auto Ic, auto Jc, const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2]) {
         constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
+        constexpr bool FIRST = decltype(Fc)::value && !(CM3P_G8P_ABL & 4);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[I * 4 + mt][J * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[mt][kk], acc[I * 4 + mt][J * 2 + nt], 0, 0, 0);
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 c = (FIRST && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[I * 4 + mt][J * 2 + nt];
+                    acc[I * 4 + mt][J * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[mt][kk], c, 0, 0, 0);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    auto ktile = [&](int par) {
-        const int pofs = par << 16;                            // this k-tile's four slots
+    // (one code path for both k-tile parities - the parity is a run-time 64 KiB offset: accumulators written in two branches
+    //  that merge are duplicated by the compiler and spilled)
+    auto ktile = [&](int par, auto Fc) {
+        const int pofs = par << 16;                                         // this k-tile's four slots
         const uint32_t lds_p = ldsw + pofs, lds_q = ldsw + (pofs ^ 65536);  // LDS-DMA bases: this parity / the other one
-        const int fa_p = fa_base + pofs, fb_p = fb_base + pofs;
         bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
         // ---- phase 1: quadrant (A-lo, B-lo)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fbl[nt][kk] = frag_at(fb_p, slot_off(0, kBL) + nt * 2048, kk);
+            for (int kk = 0; kk < 2; ++kk) fbl[nt][kk] = ob.frag(smem, pofs + slot_off(0, kBL), nt, kk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = frag_at(fa_p, slot_off(0, kAL) + mt * 2048, kk);
+            for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = oa.frag(smem, pofs + slot_off(0, kAL), mt, kk);
         __builtin_amdgcn_sched_barrier(0);
-        glds_s<slot_off(0, kAH)>(voffa, sah[0], lds_q);
-        glds_s<slot_off(0, kAH) + 1024>(voffa, sah[1], lds_q);
-        G8P_WAIT_LGKM(8);  // the four B-lo reads (issued first) are done: B-lo may be restaged in the next phase
+        glds_s<slot_off(0, kAH)>(vah, sah[0], lds_q);
+        glds_s<slot_off(0, kAH) + 1024>(vah, sah[1], lds_q);
+        // the B-lo reads (issued first) are done, so B-lo may be restaged in the next phase: at most as many LDS operations
+        // outstanding as were issued behind them (8 ds_read_b128 or 16 ds_read_b64_tr_b16; the counter holds 15)
+        if constexpr (A_KC) G8P_WAIT_LGKM(8);
+        else G8P_WAIT_LGKM(15);
         __builtin_amdgcn_s_barrier();
         G8P_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(I0{}, I0{}, fa, fbl);
+        mma(Fc, I0{}, I0{}, fa, fbl);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: (A-lo, B-hi)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fbh[nt][kk] = frag_at(fb_p, slot_off(0, kBH) + nt * 2048, kk);
+            for (int kk = 0; kk < 2; ++kk) fbh[nt][kk] = ob.frag(smem, pofs + slot_off(0, kBH), nt, kk);
         __builtin_amdgcn_sched_barrier(0);
-        glds_s<slot_off(0, kBL)>(voffb, sb[0][0], lds_p);
-        glds_s<slot_off(0, kBL) + 1024>(voffb, sb[0][1], lds_p);
+        ob.template stage<slot_off(0, kBL)>(0, lds_p);
         __builtin_amdgcn_s_barrier();
         G8P_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(I0{}, I1{}, fa, fbh);
+        mma(Fc, I0{}, I1{}, fa, fbh);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- phase 3: (A-hi, B-hi)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = frag_at(fa_p, slot_off(0, kAH) + mt * 2048, kk);
+            for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = oa.frag(smem, pofs + slot_off(0, kAH), mt, kk);
         __builtin_amdgcn_sched_barrier(0);
-        glds_s<slot_off(0, kAL)>(voffa, sa[0][0], lds_p);
-        glds_s<slot_off(0, kAL) + 1024>(voffa, sa[0][1], lds_p);
+        oa.template stage<slot_off(0, kAL)>(0, lds_p);
         __builtin_amdgcn_s_barrier();
         G8P_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(I1{}, I1{}, fa, fbh);
+        mma(Fc, I1{}, I1{}, fa, fbh);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- phase 4: (A-hi, B-lo); the counted wait retires every half-tile of the next k-tile
-        glds_s<slot_off(0, kBH)>(voffb, sb[1][0], lds_p);
-        glds_s<slot_off(0, kBH) + 1024>(voffb, sb[1][1], lds_p);
+        ob.template stage<slot_off(0, kBH)>(1, lds_p);
         stream_advance();
-        G8P_WAIT_VM(6);
+        if constexpr (!(CM3P_G8P_ABL & 8)) G8P_WAIT_VM(6);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma(I1{}, I0{}, fa, fbl);
+        mma(Fc, I1{}, I0{}, fa, fbl);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
 
     char* ebuf = smem + kRing + wid * kEpiWave;
-    int par = 0;
-    for (int v = blockIdx.x; v < total; v += gridDim.x) {
-        int64_t m0, n0;
-        int z;
-        decode(v, m0, n0, z);
-        const int64_t kbeg = (int64_t)z * kchunk;
-        const int nk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            ktile(par);
-            par ^= 1;
-        }
 
-        // ---- epilogue: per wave, 16 rows at a time through the wave's own 4 KiB of LDS (fragment layout -> whole rows), no barrier
+    // ---- epilogue: per wave, 16 rows at a time through the wave's own 4 KiB of LDS (fragment layout -> whole rows -> 16-byte
+    // stores of full 128-byte lines), no workgroup barrier.  FULL: the tile lies inside the matrix, nothing is guarded.
+    // Global addresses are a wave-uniform tile origin plus a 32-bit lane offset.
+    auto epilogue = [&](auto Fc, int64_t m0, int64_t n0, int z) {
+        constexpr bool FULL = decltype(Fc)::value;
+        // the lane id is laundered so that the epilogue's address arithmetic is not hoisted out of the work-item loop and kept
+        // alive (in registers the k-loop needs) across it
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
         const int64_t mw = m0 + wr * 128, nw = n0 + wc * 64;
-        if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
-            uint16_t* C = static_cast<uint16_t*>(Cv);
+        if constexpr (CM3P_G8P_ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if constexpr (EPI == CM3P_EPI_BF16 || EPI == CM3P_EPI_BF16_ROPE) {
+            char* Cb = reinterpret_cast<char*>(static_cast<uint16_t*>(Cv) + mw * ldc + nw);
+            const uint32_t ldcb = (uint32_t)ldc * 2;
             const bool rotate = (EPI == CM3P_EPI_BF16_ROPE) && nw < rope.ncols;  // a wave's 64 columns are one head
+            const float qs = (EPI == CM3P_EPI_BF16_ROPE && nw < rope.q_cols) ? rope.q_scale : 1.f;
+            uint32_t prow0 = 0;
+            if constexpr (EPI == CM3P_EPI_BF16_ROPE) prow0 = rope.per_batch ? 0u : (uint32_t)mw % (uint32_t)rope.S;  // M < 2^31 (checked by the caller)
 #pragma unroll
             for (int i4 = 0; i4 < 8; ++i4) {
                 char* eb = ebuf + (i4 & 1) * 2048;
@@ -262,12 +328,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     *reinterpret_cast<uint2*>(eb + row * 128 + s8 * 8) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
                 }
                 if (rotate) {
+                    // rotary embedding at store time on the bf16-rounded projection (what the reference's autocast path computes):
+                    // a lane takes (row, dims d..d+7 and d+32..d+39) of the wave's head; one table read serves both chunks
                     const int row = lane >> 2, dc = lane & 3;
-                    const int64_t m = mw + i4 * 16 + row;
-                    const uint4 xa = *reinterpret_cast<const uint4*>(eb + row * 128 + ((dc ^ (row & 7)) << 4));
-                    const uint4 xb = *reinterpret_cast<const uint4*>(eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4));
-                    if (m < M) {
-                        const int64_t prow = rope.per_batch ? m : (int64_t)((uint32_t)m % (uint32_t)rope.S);
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(eb + row * 128 + ((dc ^ (row & 7)) << 4));
+                    const u32x4 xb = *reinterpret_cast<const u32x4*>(eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4));
+                    if (FULL || mw + i4 * 16 + row < M) {
+                        int64_t prow;
+                        if (rope.per_batch) prow = mw + i4 * 16 + row;
+                        else {
+                            uint32_t x = prow0 + i4 * 16 + row;
+                            if (rope.S >= 256) x = x >= (uint32_t)rope.S ? x - (uint32_t)rope.S : x;
+                            else x %= (uint32_t)rope.S;
+                            prow = x;
+                        }
                         const float* cr = rope.cos + prow * 32 + dc * 8;
                         const float* sr = rope.sin + prow * 32 + dc * 8;
                         const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
@@ -276,44 +350,47 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                         const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                         const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
                         uint32_t oa[4], ob[4];
-                        const float qs = nw < rope.q_cols ? rope.q_scale : 1.f;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const float a0 = bf16lo(wa[t]), a1 = bf16hi(wa[t]), b0 = bf16lo(wb[t]), b1 = bf16hi(wb[t]);
                             oa[t] = pack_bf16x2(qs * (a0 * cs[2 * t] - b0 * sn[2 * t]), qs * (a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]));
                             ob[t] = pack_bf16x2(qs * (b0 * cs[2 * t] + a0 * sn[2 * t]), qs * (b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]));
                         }
-                        uint16_t* dst = C + m * ldc + nw + dc * 8;
-                        *reinterpret_cast<uint4*>(dst) = uint4{oa[0], oa[1], oa[2], oa[3]};
-                        *reinterpret_cast<uint4*>(dst + 32) = uint4{ob[0], ob[1], ob[2], ob[3]};
+                        char* dst = Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16;
+                        G8P_GLOBAL(*reinterpret_cast<u32x4*>(dst) = (u32x4{oa[0], oa[1], oa[2], oa[3]}));
+                        G8P_GLOBAL(*reinterpret_cast<u32x4*>(dst + 64) = (u32x4{ob[0], ob[1], ob[2], ob[3]}));
                     }
                 } else {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int row = u * 8 + (lane >> 3), ch = lane & 7;
-                        const uint4 x = *reinterpret_cast<const uint4*>(eb + row * 128 + ((ch ^ (row & 7)) << 4));
-                        const int64_t m = mw + i4 * 16 + row, n = nw + ch * 8;
-                        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = x;
-                    }
+                    const int r0 = lane >> 3, r1 = 8 + (lane >> 3), ch = lane & 7;
+                    const u32x4 x0 = *reinterpret_cast<const u32x4*>(eb + r0 * 128 + ((ch ^ (r0 & 7)) << 4));
+                    const u32x4 x1 = *reinterpret_cast<const u32x4*>(eb + r1 * 128 + ((ch ^ (r1 & 7)) << 4));
+                    const bool col_ok = FULL || nw + ch * 8 < N;
+                    if (FULL || (col_ok && mw + i4 * 16 + r0 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r0) * ldcb + ch * 16) = x0);
+                    if (FULL || (col_ok && mw + i4 * 16 + r1 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r1) * ldcb + ch * 16) = x1);
+                    if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x0), "v"(x1));
                 }
             }
         } else {
-            float* C = static_cast<float*>(Cv) + (int64_t)z * c_split_stride;
+            char* Cb = reinterpret_cast<char*>(static_cast<float*>(Cv) + (int64_t)z * c_split_stride + mw * ldc + nw);
+            const char* Rb = reinterpret_cast<const char*>(R + mw * ldc + nw);
+            const uint32_t ldcb = (uint32_t)ldc * 4;
+            const int lrow = lane >> 4, lch = lane & 15;
+            const uint32_t loff = (uint32_t)lrow * ldcb + lch * 16;
+            const bool col_ok = FULL || nw + lch * 4 < N;
             f32x4 rnext[4];
             auto load_r = [&](int i4) {
-                if constexpr (EPI == CM3P_EPI_F32_RESID) {
+                if constexpr (EPI == CM3P_EPI_F32_RESID && !(CM3P_G8P_ABL & 1)) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int row = u * 4 + (lane >> 4), ch = lane & 15;
-                        const int64_t m = mw + i4 * 16 + row, n = nw + ch * 4;
-                        rnext[u] = (m < M && n < N) ? *reinterpret_cast<const f32x4*>(R + m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int row = i4 * 16 + u * 4;
+                        rnext[u] = (FULL || (col_ok && mw + row + lrow < M)) ? *reinterpret_cast<const f32x4*>(Rb + loff + (uint32_t)row * ldcb)
+                                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
             };
             f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == CM3P_EPI_F32_BIAS) {
-                const int64_t n = nw + (lane & 15) * 4;
-                if (n < N) bias = *reinterpret_cast<const f32x4*>(R + n);
+                if (col_ok) bias = *reinterpret_cast<const f32x4*>(R + nw + lch * 4);
             }
             load_r(0);
 #pragma unroll
@@ -323,26 +400,46 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     const int row = lane & 15, ch = j4 * 4 + (lane >> 4);
                     *reinterpret_cast<f32x4*>(ebuf + row * 256 + ((ch ^ row) << 4)) = acc[i4][j4];
                 }
-                f32x4 rcur[4];
+                f32x4 x[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rcur[u] = rnext[u];
+                for (int u = 0; u < 4; ++u) {
+                    const int row = u * 4 + lrow;
+                    x[u] = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + ((lch ^ row) << 4));
+                    if constexpr (EPI == CM3P_EPI_F32_RESID && !(CM3P_G8P_ABL & 1)) x[u] += rnext[u];
+                    if constexpr (EPI == CM3P_EPI_F32_BIAS) x[u] += bias;
+                }
                 if (i4 < 7) load_r(i4 + 1);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int row = u * 4 + (lane >> 4), ch = lane & 15;
-                    f32x4 x = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + ((ch ^ row) << 4));
-                    const int64_t m = mw + i4 * 16 + row, n = nw + ch * 4;
-                    if constexpr (EPI == CM3P_EPI_F32_RESID) x += rcur[u];
-                    if constexpr (EPI == CM3P_EPI_F32_BIAS) x += bias;
-                    if (m < M && n < N) *reinterpret_cast<f32x4*>(C + m * ldc + n) = x;
+                    const int row = i4 * 16 + u * 4;
+                    if (FULL || (col_ok && mw + row + lrow < M)) G8P_GLOBAL(*reinterpret_cast<f32x4*>(Cb + loff + (uint32_t)row * ldcb) = x[u]);
+                    if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x[u]));
                 }
             }
         }
+    };
+
+    int par = 0;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        int64_t m0, n0;
+        int z;
+        decode(v, m0, n0, z);
+        const int64_t kbeg = (int64_t)z * kchunk;
+        const int nk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
+        ktile(par, std::true_type{});
+        par ^= 1;
+        for (int kt = 1; kt < nk; ++kt) {
+            ktile(par, std::false_type{});
+            par ^= 1;
+        }
+        if (m0 + 256 <= M && n0 + 256 <= N) epilogue(std::true_type{}, m0, n0, z);
+        else epilogue(std::false_type{}, m0, n0, z);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier
     G8P_WAIT_VM(0);                             // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+template <bool A_KC, bool B_KC>
 int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
              int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
@@ -359,18 +456,28 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            if (hipFuncSetAttribute((const void*)gemm8p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
+            if (hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
                 return CM3P_ERR_LAUNCH;                                                                                           \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm8p_kernel<E><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
+        gemm8p_kernel<A_KC, B_KC, E><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G8P(CM3P_EPI_BF16) break;
         case CM3P_EPI_F32: CM3P_G8P(CM3P_EPI_F32) break;
         case CM3P_EPI_F32_RESID: CM3P_G8P(CM3P_EPI_F32_RESID) break;
-        case CM3P_EPI_BF16_ROPE: CM3P_G8P(CM3P_EPI_BF16_ROPE) break;
-        case CM3P_EPI_F32_BIAS: CM3P_G8P(CM3P_EPI_F32_BIAS) break;
+        case CM3P_EPI_BF16_ROPE:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G8P(CM3P_EPI_BF16_ROPE)
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        case CM3P_EPI_F32_BIAS:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G8P(CM3P_EPI_F32_BIAS)
+                break;
+            }
+            return CM3P_ERR_INVALID;
         default: return CM3P_ERR_INVALID;
     }
 #undef CM3P_G8P
@@ -383,9 +490,15 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
 int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk, int64_t c_split_stride,
                          hipStream_t s, RopeArgs rope) {
-    if (!(a_kc && b_kc)) return CM3P_ERR_INVALID;
     if (M % 8 != 0 || N % 8 != 0 || K % 64 != 0 || kchunk % 64 != 0) return CM3P_ERR_INVALID;
-    if (lda * 2 * 8 >= (int64_t(1) << 31) || ldb * 2 * 8 >= (int64_t(1) << 31)) return CM3P_ERR_INVALID;
-    return launch8p(static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk,
-                    c_split_stride, s, rope);
+    if (lda * 2 * 8 >= (int64_t(1) << 31) || ldb * 2 * 8 >= (int64_t(1) << 31)) return CM3P_ERR_INVALID;  // 32-bit lane offsets
+    const uint16_t* a = static_cast<const uint16_t*>(A);
+    const uint16_t* b = static_cast<const uint16_t*>(B);
+    if (a_kc && b_kc) return launch8p<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (a_kc) return launch8p<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    if (b_kc) return launch8p<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    return launch8p<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
 }
+
+// timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
+int cm3p_ablation_flags_gemm8p() { return (CM3P_G8P_ABL); }

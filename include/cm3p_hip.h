@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 10
+#define CM3P_ABI_VERSION 11
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -95,6 +95,12 @@ int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int3
  * all tokens while its output is only a few hundred tiles. */
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
+
+/* Host-only.  The hand-scheduled kernels carry compile-time TIMING probes (macros CM3P_ABL, CM3P_FABL, CM3P_BABL, CM3P_G256_ABL,
+ * CM3P_G8P_ABL: builds that skip barriers, loads or stores and whose results are wrong by construction; the _ablate.sh scripts under tools/ubench).
+ * Returns a bit mask of the objects in THIS library that were built with any of them set: 0 for every library that may be used
+ * for results (cm3p_amd/_lib.py refuses to load anything else; tests/test_cabi.py). */
+int cm3p_build_ablation_flags(void);
 
 /* Fused Wqkv projection + rotary embedding: qkv[M, N] (bf16) = x[M, K] Wqkv[N, K]^T with apply_rotary_pos_emb applied to the
  * first rope_cols (= 2H: the q and k thirds) columns (TF:...modeling_modernbert.py:271-280).  The 256 x 256 kernel rotates the

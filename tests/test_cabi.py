@@ -108,3 +108,29 @@ def test_fused_attention_backward_rejects_bad_arguments_without_a_gpu(lib_path):
     assert call(cos=fake, sin=None) == -1
     assert call(cu=fake, total=0) == -1  # packed rows need their total
     assert call(qkv=fake + 2) == -1  # 16-byte alignment
+
+
+def test_shipped_library_carries_no_timing_ablations(lib_path, tmp_path):
+    """The hand-scheduled kernels have compile-time timing probes (CM3P_ABL / CM3P_FABL / CM3P_BABL / CM3P_G256_ABL / CM3P_G8P_ABL)
+    whose results are wrong by construction.  The in-tree library reports a zero mask, and the binding refuses a library that
+    does not (checked on an object built with one probe set, linked with the shipped objects; compile only, no GPU)."""
+    import subprocess
+
+    from cm3p_amd import _lib, build
+
+    lib = ctypes.CDLL(lib_path)
+    assert lib.cm3p_build_ablation_flags() == 0
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    obj = tmp_path / "gemm8p_abl.o"
+    subprocess.run([hipcc, *build.FLAGS, "-DCM3P_G8P_ABL=1", "-c", os.path.join(build.CSRC, "gemm8p.hip"), "-o", str(obj)], check=True, capture_output=True)
+    objs = [os.path.join(build.CSRC, s.replace(".hip", ".o")) for s in build.SOURCES if s != "gemm8p.hip"]
+    bad = tmp_path / "libablated.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(bad), *objs, str(obj)], check=True, capture_output=True)
+    assert ctypes.CDLL(str(bad)).cm3p_build_ablation_flags() == 1 << 4
+    code = ("import os, sys; os.environ['CM3P_HIP_LIB'] = sys.argv[1]\n"
+            "from cm3p_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.Cm3pHipError as e:\n    print('REFUSED' if 'ablation' in str(e) else e)\n")
+    out = subprocess.run([os.sys.executable, "-c", code, str(bad)], capture_output=True, text=True, cwd=ROOT)
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr

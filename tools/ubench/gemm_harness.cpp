@@ -1,9 +1,10 @@
-// Stand-alone harness for the big-shape GEMM kernels (no torch): links libcm3p_hip.so, runs cm3p_gemm_bf16 with CM3P_GEMM_IMPL=256
+// Stand-alone harness for the big-shape GEMM kernels (no torch): dlopens libcm3p_hip.so (CM3P_HIP_LIB or the in-tree build), runs cm3p_gemm_bf16 with CM3P_GEMM_IMPL=256
 // and the default (gemm8p.hip) on the same operands, compares every element, checks guard zones around the output, then times both
 // in interleaved rounds.  Every buffer sits in the middle of one large allocation with 64 MiB of owned memory on both sides, so a
 // near out-of-bounds access corrupts a guard (reported) instead of faulting the GPU.
-//   hipcc -O2 -o /tmp/gemm_harness tools/ubench/gemm_harness.cpp -Lcm3p_amd/csrc -lcm3p_hip -Wl,-rpath,$PWD/cm3p_amd/csrc
-//   /tmp/gemm_harness [check] [time]
+//   hipcc --offload-arch=gfx950 -O2 -o tools/ubench/gemm_harness tools/ubench/gemm_harness.cpp -ldl
+//   tools/ubench/gemm_harness [check] [time]        (run from the repository root)
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -13,7 +14,12 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/cm3p_hip.h"
+#define CM3P_EPI_BF16 0
+#define CM3P_EPI_F32 1
+#define CM3P_EPI_F32_RESID 2
+typedef int (*gemm_fn)(const void*, const void*, void*, const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int,
+                       float*, void*);
+static gemm_fn cm3p_gemm_bf16;
 
 #define CK(x)                                                                  \
     do {                                                                       \
@@ -83,6 +89,13 @@ int main(int argc, char** argv) {
         do_check |= !strcmp(argv[i], "check");
         do_time |= !strcmp(argv[i], "time");
     }
+    const char* libpath = getenv("CM3P_HIP_LIB") ? getenv("CM3P_HIP_LIB") : "cm3p_amd/csrc/libcm3p_hip.so";
+    void* lib = dlopen(libpath, RTLD_NOW);
+    if (!lib) {
+        printf("cannot load %s: %s\n", libpath, dlerror());
+        return 2;
+    }
+    cm3p_gemm_bf16 = (gemm_fn)dlsym(lib, "cm3p_gemm_bf16");
     unsigned long long* d_cnt;
     CK(hipMalloc(&d_cnt, 8));
     struct Shape { int64_t M, N, K; };
@@ -102,17 +115,22 @@ int main(int argc, char** argv) {
             fill_bf16<<<1024, 256>>>((uint16_t*)B.p(), s.N * s.K, 2u, 1.f);
             fill_f32<<<1024, 256>>>((float*)R.p(), s.M * s.N, 3u);
             CK(hipDeviceSynchronize());
+            for (int lay = 0; lay < 4; ++lay)
             for (int e = 0; e < 3; ++e) {
+                const int a_kc = !(lay & 1), b_kc = !(lay & 2);
+                if (lay && e == 1) continue;
+                if ((!a_kc && s.M % 8) || (!b_kc && s.N % 8)) continue;
+                const int64_t lda = a_kc ? s.K : s.M, ldb = b_kc ? s.K : s.N;
                 const size_t out_bytes = s.M * s.N * (epis[e] == CM3P_EPI_BF16 ? 2 : 4);
-                printf("check [%ld x %ld x %ld] %-9s ... ", (long)s.M, (long)s.N, (long)s.K, epi_names[e]);
+                printf("check [%ld x %ld x %ld] a_kc=%d b_kc=%d %-9s ... ", (long)s.M, (long)s.N, (long)s.K, a_kc, b_kc, epi_names[e]);
                 fflush(stdout);
                 impl("256");
-                int rc0 = cm3p_gemm_bf16(A.p(), B.p(), C0.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, s.K, s.K, s.N, 1, 1, epis[e], 1, nullptr, nullptr);
+                int rc0 = cm3p_gemm_bf16(A.p(), B.p(), C0.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, lda, ldb, s.N, a_kc, b_kc, epis[e], 1, nullptr, nullptr);
                 CK(hipDeviceSynchronize());
                 printf("256 rc=%d ", rc0);
                 fflush(stdout);
                 impl("8p");
-                int rc1 = cm3p_gemm_bf16(A.p(), B.p(), C1.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, s.K, s.K, s.N, 1, 1, epis[e], 1, nullptr, nullptr);
+                int rc1 = cm3p_gemm_bf16(A.p(), B.p(), C1.p(), epis[e] == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, s.M, s.N, s.K, lda, ldb, s.N, a_kc, b_kc, epis[e], 1, nullptr, nullptr);
                 CK(hipDeviceSynchronize());
                 printf("8p rc=%d ", rc1);
                 fflush(stdout);
@@ -134,11 +152,21 @@ int main(int argc, char** argv) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        struct T { int64_t M, N, K; int epi; const char* name; };
+        struct T { int64_t M, N, K; int epi; const char* name; int a_kc = 1, b_kc = 1, splits = 1; };
         const T ts[] = {{4096, 4096, 4096, CM3P_EPI_BF16, "cube 4096 bf16"}, {8192, 8192, 8192, CM3P_EPI_BF16, "cube 8192 bf16"},
                         {131072, 2304, 768, CM3P_EPI_BF16, "Wqkv/Wi fwd bf16"}, {131072, 768, 768, CM3P_EPI_F32_RESID, "Wo fwd f32+resid"},
                         {131072, 768, 768, CM3P_EPI_BF16, "Wo-shape bf16"}, {131072, 768, 1152, CM3P_EPI_F32_RESID, "Wo2 fwd f32+resid"},
-                        {131072, 768, 2304, CM3P_EPI_BF16, "dgrad-shape K=2304 bf16 (kc,kc)"}};
+                        {131072, 768, 2304, CM3P_EPI_BF16, "dgrad-shape K=2304 bf16 (kc,kc)"},
+                        {131072, 768, 2304, CM3P_EPI_BF16, "dgrad Wqkv/Wi K=2304 bf16 (kc,ks)", 1, 0},
+                        {131072, 1152, 768, CM3P_EPI_BF16, "dgrad Wo2 K=768 N=1152 bf16 (kc,ks)", 1, 0},
+                        {131072, 768, 768, CM3P_EPI_BF16, "dgrad Wo K=768 bf16 (kc,ks)", 1, 0},
+                        {8192, 8192, 8192, CM3P_EPI_BF16, "cube 8192 (kc,ks)", 1, 0},
+                        {8192, 8192, 8192, CM3P_EPI_F32, "cube 8192 f32 (ks,ks)", 0, 0},
+                        {2304, 768, 131072, CM3P_EPI_F32, "wgrad Wqkv/Wi split 9 (ks,ks)", 0, 0, 9},
+                        {768, 768, 131072, CM3P_EPI_F32, "wgrad Wo split 28 (ks,ks)", 0, 0, 28},
+                        {768, 1152, 131072, CM3P_EPI_F32, "wgrad Wo2 split 17 (ks,ks)", 0, 0, 17}};
+        float* ws;
+        CK(hipMalloc(&ws, (size_t)28 * 2304 * 1152 * 4));
         for (const T& t : ts) {
             Guarded A, B, R, C;
             A.alloc(t.M * t.K * 2); B.alloc(t.N * t.K * 2); R.alloc(t.M * t.N * 4); C.alloc(t.M * t.N * 4);
@@ -151,10 +179,10 @@ int main(int argc, char** argv) {
                 for (int which = 0; which < 2; ++which) {
                     impl(which ? "8p" : "256");
                     const float* r = t.epi == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr;
-                    for (int i = 0; i < 3; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.K, t.K, t.N, 1, 1, t.epi, 1, nullptr, nullptr);
+                    for (int i = 0; i < 3; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.a_kc ? t.K : t.M, t.b_kc ? t.K : t.N, t.N, t.a_kc, t.b_kc, t.epi, t.splits, ws, nullptr);
                     CK(hipEventRecord(e0));
                     const int iters = 20;
-                    for (int i = 0; i < iters; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.K, t.K, t.N, 1, 1, t.epi, 1, nullptr, nullptr);
+                    for (int i = 0; i < iters; ++i) cm3p_gemm_bf16(A.p(), B.p(), C.p(), r, t.M, t.N, t.K, t.a_kc ? t.K : t.M, t.b_kc ? t.K : t.N, t.N, t.a_kc, t.b_kc, t.epi, t.splits, ws, nullptr);
                     CK(hipEventRecord(e1));
                     CK(hipEventSynchronize(e1));
                     float m;
