@@ -56,6 +56,11 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // (HIP's uint4 is 
 #else
 #define G8P_GLOBAL(stmt) stmt
 #endif
+// Compiler-only fence between the two halves of a cross-lane exchange through the wave's LDS buffer.  The hardware executes a wave's
+// LDS instructions in order, but to the compiler every lane is a thread of its own: without a fence it deletes a lane's stores that
+// the same lane never reads back (dead-store elimination: that happened on edge tiles, where the readers are masked) and may move
+// the next block's stores above this block's loads.
+#define G8P_LANE_XCHG_FENCE() asm volatile("" ::: "memory")
 #define G8P_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define G8P_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -327,12 +332,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     const int row = lane & 15, s8 = (j4 * 4 + (lane >> 4)) ^ ((row & 7) << 1);
                     *reinterpret_cast<uint2*>(eb + row * 128 + s8 * 8) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
                 }
+                G8P_LANE_XCHG_FENCE();
                 if (rotate) {
                     // rotary embedding at store time on the bf16-rounded projection (what the reference's autocast path computes):
                     // a lane takes (row, dims d..d+7 and d+32..d+39) of the wave's head; one table read serves both chunks
                     const int row = lane >> 2, dc = lane & 3;
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(eb + row * 128 + ((dc ^ (row & 7)) << 4));
                     const u32x4 xb = *reinterpret_cast<const u32x4*>(eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4));
+                    G8P_LANE_XCHG_FENCE();
                     if (FULL || mw + i4 * 16 + row < M) {
                         int64_t prow;
                         if (rope.per_batch) prow = mw + i4 * 16 + row;
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     const int r0 = lane >> 3, r1 = 8 + (lane >> 3), ch = lane & 7;
                     const u32x4 x0 = *reinterpret_cast<const u32x4*>(eb + r0 * 128 + ((ch ^ (r0 & 7)) << 4));
                     const u32x4 x1 = *reinterpret_cast<const u32x4*>(eb + r1 * 128 + ((ch ^ (r1 & 7)) << 4));
+                    G8P_LANE_XCHG_FENCE();
                     const bool col_ok = FULL || nw + ch * 8 < N;
                     if (FULL || (col_ok && mw + i4 * 16 + r0 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r0) * ldcb + ch * 16) = x0);
                     if (FULL || (col_ok && mw + i4 * 16 + r1 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r1) * ldcb + ch * 16) = x1);
@@ -400,11 +408,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     const int row = lane & 15, ch = j4 * 4 + (lane >> 4);
                     *reinterpret_cast<f32x4*>(ebuf + row * 256 + ((ch ^ row) << 4)) = acc[i4][j4];
                 }
+                G8P_LANE_XCHG_FENCE();
                 f32x4 x[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = u * 4 + lrow;
                     x[u] = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + ((lch ^ row) << 4));
+                }
+                G8P_LANE_XCHG_FENCE();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
                     if constexpr (EPI == CM3P_EPI_F32_RESID && !(CM3P_G8P_ABL & 1)) x[u] += rnext[u];
                     if constexpr (EPI == CM3P_EPI_F32_BIAS) x[u] += bias;
                 }
