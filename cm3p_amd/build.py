@@ -25,7 +25,10 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, check_isa: bool = True) -> str:
+    """Compile what is stale and link.  Objects whose correctness depends on the emitted instruction pattern (counted vmcnt rings,
+    inline-asm MFMAs: isa_check.CHECKS) are re-checked every time they are recompiled; a failed check fails the build, so a
+    different hipcc or flag set cannot silently ship a kernel whose waits no longer cover its loads."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "..", "..", "include", "cm3p_hip.h")]
     objs = []
@@ -39,9 +42,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
+    checks = []
+    if check_isa:
+        from . import isa_check
+
+        for src, _ in procs:
+            if src in isa_check.CHECKS:
+                cmd = [hipcc, *[f for f in FLAGS if f != "-Wall"], *EXTRA_FLAGS.get(src, []), "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, src)]
+                checks.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+    for src, p in checks:
+        isa, _ = p.communicate()
+        try:
+            if p.returncode != 0:
+                raise RuntimeError(f"hipcc -S failed on {src}")
+            isa_check.CHECKS[src](isa)
+        except Exception:
+            os.remove(os.path.join(CSRC, src.replace(".hip", ".o")))  # never link (or leave behind) an unchecked object
+            raise
+        if verbose:
+            print(f"ISA pattern of {src}: ok", flush=True)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:

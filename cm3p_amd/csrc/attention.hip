@@ -710,6 +710,7 @@ int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
     CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
+    CM3P_REQUIRE((int64_t)S * 3 * nh * 128 < (int64_t(1) << 31));  // TileDma::rows: 32-bit row * pitch source offsets (attn_common.h)
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, window, scale, cos_tab, sin_tab,
                                    pos_batch_stride, VarLen{nullptr, 0}, stages, q_prescaled != 0, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
@@ -735,6 +736,7 @@ int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, con
     CM3P_REQUIRE(stages >= 1 && stages <= 3);
     CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && cu_seqlens && B > 0 && max_seqlen > 0 && total > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
+    CM3P_REQUIRE((int64_t)max_seqlen * 3 * nh * 128 < (int64_t(1) << 31));  // TileDma::rows: 32-bit row * pitch source offsets
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, nullptr, B, max_seqlen, nh, window, scale, cos_tab, sin_tab, 0,
                                    VarLen{cu_seqlens, total}, stages, q_prescaled != 0, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;

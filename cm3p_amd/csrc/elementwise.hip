@@ -38,6 +38,39 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     }
 }
 
+// bf16 copy of an fp32 [rows, cols] matrix AND its transpose [cols, rows] in one pass: 64 x 64 tiles through LDS (each element is
+// rounded once; both outputs hold the same bf16 values).  rows, cols multiples of 8.
+__global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, uint16_t* __restrict__ yt,
+                                                              int rows, int cols, int tiles_c) {
+    __shared__ uint16_t tile[64][66];  // 66: a column walk touches a different bank pair per row
+    const int r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // 64 rows x 16 float4
+        const int r = it * 16 + (tid >> 4), c = (tid & 15) * 4;
+        if (r0 + r < rows && c0 + c < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + r) * cols + c0 + c);
+            const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+            *reinterpret_cast<uint2*>(y + (int64_t)(r0 + r) * cols + c0 + c) = uint2{lo, hi};
+            tile[r][c] = (uint16_t)lo;
+            tile[r][c + 1] = (uint16_t)(lo >> 16);
+            tile[r][c + 2] = (uint16_t)hi;
+            tile[r][c + 3] = (uint16_t)(hi >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {  // 64 transposed rows x 8 chunks of 8 elements
+        const int c = it * 32 + (tid >> 3), r = (tid & 7) * 8;
+        if (c0 + c < cols && r0 + r < rows) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[r + 2 * k][c] | ((uint32_t)tile[r + 2 * k + 1][c] << 16);
+            *reinterpret_cast<uint4*>(yt + (int64_t)(c0 + c) * rows + r0 + r) = uint4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
 template <bool B_BF16>
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const void* __restrict__ b, float* y32,
                                                       uint16_t* __restrict__ y16, int64_t n4) {
@@ -255,6 +288,15 @@ int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
     CM3P_REQUIRE(x && y && n >= 0 && n % 4 == 0);
     if (n == 0) return CM3P_OK;
     cast_f32_bf16_kernel<<<ew_grid(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(x, (uint16_t*)y, n / 4);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_cast_f32_bf16_t(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream) {
+    CM3P_REQUIRE(x && y && y_t && rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0 && rows < (1 << 24) && cols < (1 << 24));
+    CM3P_REQUIRE(cm3p_aligned16(x) && cm3p_aligned16(y) && cm3p_aligned16(y_t));
+    const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((cols + 63) / 64);
+    cast_f32_bf16_t_kernel<<<tiles_r * tiles_c, 256, 0, static_cast<hipStream_t>(stream)>>>(x, (uint16_t*)y, (uint16_t*)y_t, (int)rows, (int)cols, tiles_c);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

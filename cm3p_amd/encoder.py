@@ -92,6 +92,16 @@ def _bf16_weight(w: Tensor) -> Tensor:
     return K.cast_bf16(w.contiguous())
 
 
+def _bf16_weight_pair(w: Tensor, want_t: bool):
+    """-> (bf16 W [out, in], bf16 W^T [in, out] or None).  The transpose feeds the input-gradient GEMM (dx = dy W) with the
+    contraction index contiguous in both operands; it is made in the same pass as the cast when a backward will follow and the
+    extents allow it (multiples of 8), otherwise dgrad reads W itself (k-strided operand, same result)."""
+    w = w.detach()
+    if want_t and w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+        return K.cast_bf16_with_transpose(w.contiguous())
+    return _bf16_weight(w), None
+
+
 class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
@@ -157,13 +167,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         it = iter(weights)
         w_an = None if i == 0 else _f32(next(it))
         Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
-        wb = (w_an, *(_bf16_weight(w) for w in (Wqkv, Wo)), w_mn, *(_bf16_weight(w) for w in (Wi, Wo2)))
+        pairs = [_bf16_weight_pair(w, geo.save) for w in (Wqkv, Wo, Wi, Wo2)]
+        wb = (w_an, pairs[0][0], pairs[1][0], w_mn, pairs[2][0], pairs[3][0])
         x_out, acts = _layer_forward(geo, i, x, wb, geo.save)
         if geo.save:
             # gradient checkpointing (ref: supports_gradient_checkpointing, TF GradientCheckpointingLayer): keep only the
             # layer input; its activations are recomputed by the same kernels (bit-identical) in the backward pass
             ctx.saved = (x,) if geo.checkpoint else acts
             ctx.geo, ctx.i, ctx.wb = geo, i, wb
+            ctx.wt = tuple(p[1] for p in pairs)  # W^T copies for the input-gradient GEMMs
             ctx.wdtypes = [w.dtype for w in weights]
         return x_out
 
@@ -185,19 +197,20 @@ class _EncoderLayerFn(torch.autograd.Function):
         x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = acts
         del acts
         w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb
-        ctx.saved = ctx.wb = None  # release activations as we go
+        Wqkv_t, Wo_t, Wi_t, Wo2_t = ctx.wt
+        ctx.saved = ctx.wb = ctx.wt = None  # release activations as we go
         # ---- MLP branch: x_out = x_mid + g Wo2^T
-        dg = K.linear_dgrad(gx16, Wo2_b)
+        dg = K.linear_dgrad(gx16, Wo2_b, Wo2_t)
         dWo2 = K.linear_wgrad(gx16, g) if n_o2 else None
         dh = K.geglu_bwd(dg, h)
         del dg, g
-        dxn2 = K.linear_dgrad(dh, Wi_b)
+        dxn2 = K.linear_dgrad(dh, Wi_b, Wi_t)
         dWi = K.linear_wgrad(dh, xn2) if n_i else None
         del dh, h, xn2
         gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True)
         del dxn2, x_mid
         # ---- attention branch: x_mid = x + o Wo^T
-        do = K.linear_dgrad(gx16, Wo_b)
+        do = K.linear_dgrad(gx16, Wo_b, Wo_t)
         dWo = K.linear_wgrad(gx16, o) if n_o else None
         # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
         if geo.cu is not None:
@@ -210,11 +223,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         if i == 0:
             dw_an = None
             if need[2]:
-                dxn = K.linear_dgrad(dqkv, Wqkv_b)
+                dxn = K.linear_dgrad(dqkv, Wqkv_b, Wqkv_t)
                 gx32, _ = K.add_f32(gx32, dxn, want_bf16=False)
             _hand_upstream(geo, gx32, None)
         elif need[2] or n_an:
-            dxn = K.linear_dgrad(dqkv, Wqkv_b)
+            dxn = K.linear_dgrad(dqkv, Wqkv_b, Wqkv_t)
             gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True)
             _hand_upstream(geo, gx32, gx16)
         else:  # everything below this layer is frozen: the chain ends here
@@ -475,11 +488,13 @@ class CM3PEncoder(nn.Module):
         dev = input_ids.device
         ids = input_ids.to(torch.int64).contiguous()
         total = ids.numel()
-        cu = cu_seqlens.to(device=dev, dtype=torch.int32).contiguous()
+        cu = cu_seqlens.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        if cu.numel() < 2:
+            raise ValueError("cu_seqlens needs at least two entries (batch + 1)")
         lens = cu[1:] - cu[:-1]
         # ONE host read validates the description (a wrong cu_seqlens would send the kernels past the rows)
-        last, mx, mn = torch.stack((cu[-1], lens.max(), lens.min())).tolist()
-        if int(cu[0]) != 0 or last != total or mn <= 0:
+        first, last, mx, mn = torch.stack((cu[0], cu[-1], lens.max(), lens.min())).tolist()
+        if first != 0 or last != total or mn <= 0:
             raise ValueError(f"cu_seqlens must start at 0, increase strictly and end at the token count ({total}); got end {last}, min length {mn}")
         max_s = int(mx) if max_seqlen is None else int(max_seqlen)
         if max_s < mx:

@@ -1,0 +1,128 @@
+"""Compile-time checks of the generated ISA for the kernels whose CORRECTNESS depends on what hipcc emits (no GPU needed).
+
+Three files synchronise LDS-DMA rings with counted `s_waitcnt vmcnt(N)` and / or issue inline-asm MFMAs that hipcc pads no
+hazards for: attention_bwd.hip, attention_bwd_fused.hip and gemm8p.hip.  A different hipcc, other flags or an innocent source edit
+can add a spill reload, a scratch access or an accumulator copy to their loops; the counted waits then cover the wrong loads and
+the results are silently wrong.  `build.py` runs these checks whenever it recompiles one of the files (a failed check fails the
+build) and tests/test_kernel_isa.py runs them on every test run.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+class IsaCheckError(AssertionError):
+    pass
+
+
+def _need(cond, msg):
+    if not cond:
+        raise IsaCheckError(msg)
+
+
+def compile_isa(src: str, flags: list[str], hipcc: str | None = None) -> str:
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *[f for f in flags if f != "-Wall"], "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, src)]
+    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+
+
+def kernel_bodies(isa: str, name: str) -> dict[str, str]:
+    """mangled symbol -> text of every kernel whose mangled name contains `name` (comment lines and inline-asm markers removed)."""
+    isa = re.sub(r"^\s*;.*\n", "", isa, flags=re.M)
+    out = {}
+    for m in re.finditer(r"^(_ZN\S*" + re.escape(name) + r"\S*):", isa, re.M):
+        out[m.group(1)] = isa[m.start():isa.index(".Lfunc_end", m.start())]
+    return out
+
+
+def no_scratch(isa: str, what: str):
+    for key in ("private_segment_fixed_size", "vgpr_spill_count"):
+        for m in re.finditer(r"\." + key + r":\s*(\d+)", isa):
+            _need(int(m.group(1)) == 0, f"{what}: {key} = {m.group(1)} (a spilled register turns ring loads into synchronous round trips "
+                                         "and breaks the counted vmcnt waits)")
+
+
+def loops(body: str):
+    """(label, text) of every backward branch target .. branch segment."""
+    labels = {m.group(1): m.start() for m in re.finditer(r"^(\.LBB\d+_\d+):", body, re.M)}
+    for m in re.finditer(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", body):
+        if m.group(1) in labels and labels[m.group(1)] < m.start():
+            yield m.group(1), body[labels[m.group(1)]:m.start()]
+
+
+# ------------------------------------------------------------------------------------------------ gemm8p.hip
+def check_gemm8p(isa: str):
+    """The half-tile ring of gemm8p.hip: per k-tile exactly 8 LDS-DMA instructions (4 half-tiles x 2 pieces per wave), 8 raw
+    barriers, 64 MFMAs and ONE vector-memory wait, `s_waitcnt vmcnt(6)`, right in front of a barrier; the B-lo fragment reads are
+    retired by `lgkmcnt(8 | 15)` in front of the first barrier of phase 1; no scratch anywhere."""
+    no_scratch(isa, "gemm8p.hip")
+    bodies = kernel_bodies(isa, "gemm8p_kernel")
+    _need(len(bodies) >= 12, f"gemm8p.hip: {len(bodies)} kernel instances found")
+    for sym, body in bodies.items():
+        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_16x16x32_bf16") == 64]
+        _need(ring, f"{sym}: steady-state k-tile loop (64 MFMAs) not found")
+        seg = min(ring, key=len)
+        dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", seg))
+        _need(dma == 8, f"{sym}: {dma} LDS-DMA instructions per k-tile, expected 8")
+        _need(seg.count("s_barrier") == 8, f"{sym}: {seg.count('s_barrier')} barriers per k-tile, expected 8")
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", seg)
+        _need(waits == ["6"], f"{sym}: vector-memory waits in the k-tile loop are {waits}, expected one vmcnt(6)")
+        m = re.search(r"s_waitcnt vmcnt\(6\)", seg)
+        _need(re.match(r"\s*s_barrier", seg[m.end():]), f"{sym}: the counted wait is not directly in front of a barrier")
+        _need("scratch_" not in seg and not re.search(r"\b(buffer_|flat_|global_load_dword|global_store)", seg),
+              f"{sym}: stray memory instruction in the k-tile loop")
+        lg = re.findall(r"s_waitcnt lgkmcnt\((8|15)\)\s*\n\s*s_barrier", seg)
+        _need(len(lg) == 1, f"{sym}: the B-lo retire wait (lgkmcnt(8|15) in front of phase 1's barrier) appears {len(lg)} times")
+        # whole kernel: prologue 14 pieces + two k-tile bodies (first / steady) of 8
+        total = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
+        _need(total == 30, f"{sym}: {total} LDS-DMA instructions in the kernel, expected 14 + 8 + 8")
+        _need(body.count("s_waitcnt vmcnt(0)") >= 1, f"{sym}: the final drain of the ring is missing")
+
+
+# ------------------------------------------------------------------------------------------------ attention_bwd.hip
+def check_attention_bwd(isa: str):
+    no_scratch(isa, "attention_bwd.hip")
+    for name, mfma_per_block in (("attn_bwd_dkv3_kernel", 64), ("attn_bwd_dq3_kernel", 48)):
+        for sym, body in kernel_bodies(isa, name).items():
+            blocks = [b for b in re.split(r"\n(?=\.LBB\d+_\d+:)", body) if b.count("v_mfma_f32_32x32x16_bf16") >= mfma_per_block]
+            _need(blocks, f"{sym}: main loop not found")
+            for b in blocks:
+                _need("v_accvgpr_write" not in b and "v_accvgpr_read" not in b, f"{sym}: accumulator copies in the main loop "
+                                                                                 "(an AGPR operand re-materialised in front of an asm MFMA is read stale)")
+                _need("scratch_" not in b, f"{sym}: scratch access in the main loop")
+                _need(re.search(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], v\[\d+:\d+\], a\[\d+:\d+\]", b), f"{sym}: VGPR-result MFMA form missing")
+                _need(re.search(r"v_mfma_f32_32x32x16_bf16 a\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], a\[\d+:\d+\]", b), f"{sym}: AGPR-accumulating MFMA form missing")
+
+
+# ------------------------------------------------------------------------------------------------ attention_bwd_fused.hip
+def check_attention_bwd_fused(isa: str):
+    no_scratch(isa, "attention_bwd_fused.hip")
+    for variant in ("ILb1E", "ILb0E"):
+        bodies = kernel_bodies(isa, "attn_bwd_fused_kernel" + variant)
+        _need(len(bodies) == 1, f"attn_bwd_fused_kernel{variant}: {len(bodies)} instances")
+        sym, body = next(iter(bodies.items()))
+        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_32x32x16_bf16") == 480]
+        _need(ring, f"{sym}: unrolled six-tile ring not found")
+        ring = ring[-1]
+        _need("v_accvgpr_write" not in ring and "v_accvgpr_read" not in ring and "scratch_" not in ring, f"{sym}: accumulator copies / scratch in the ring")
+        _need(ring.count("global_load_lds_dwordx4") == 24 and ring.count("global_load_lds_dword ") == 6, f"{sym}: LDS-DMA count per ring changed")
+        _need(len(re.findall(r"\bglobal_store_dwordx4\b", ring)) == 12 and len(re.findall(r"\bglobal_(load|store)_", ring)) == 42,
+              f"{sym}: vector-memory instruction count per ring changed")
+        _need(not re.search(r"\bbuffer_|\bflat_", ring), f"{sym}: buffer / flat instruction in the ring")
+        _need(ring.count("s_barrier") == 6, f"{sym}: barriers per ring")
+        _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == ["9"] * 6 and "vmcnt(0)" not in ring, f"{sym}: the ring's waits are not six vmcnt(9)")
+        for m in re.finditer(r"s_barrier", ring):
+            _need("vmcnt(9)" in ring[max(0, m.start() - 400):m.start()], f"{sym}: a barrier without its counted wait")
+        _need(re.search(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\]", ring), f"{sym}: dQ MFMA form")
+        _need(ring.count("v_exp_f32") == 384 and len(re.findall(r"v_exp_f32_e64 v\d+, v\d+ clamp", ring)) == 384, f"{sym}: exponentials / clamp")
+
+
+CHECKS = {"gemm8p.hip": check_gemm8p, "attention_bwd.hip": check_attention_bwd, "attention_bwd_fused.hip": check_attention_bwd_fused}
+
+
+def check_file(src: str, flags: list[str]) -> None:
+    CHECKS[src](compile_isa(src, flags))

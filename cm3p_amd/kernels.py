@@ -136,10 +136,13 @@ def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_
     return out
 
 
-def linear_dgrad(dy: Tensor, w: Tensor) -> Tensor:
-    """dy [T,N] bf16, w [N,K] bf16 -> dx [T,K] bf16 = dy w."""
+def linear_dgrad(dy: Tensor, w: Tensor, w_t: Optional[Tensor] = None) -> Tensor:
+    """dy [T,N] bf16, w [N,K] bf16 -> dx [T,K] bf16 = dy w.  With w_t = w^T [K,N] (cast_bf16_with_transpose) the contraction index
+    is contiguous in both operands - the faster form of the 256 x 256 kernel (same products, same accumulation order)."""
     T, N = dy.shape
     K = w.shape[1]
+    if w_t is not None:
+        return gemm(dy, w_t, T, K, N, True, True, EPI_BF16)
     return gemm(dy, w, T, K, N, True, False, EPI_BF16)
 
 
@@ -154,6 +157,15 @@ def cast_bf16(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     call("cm3p_cast_f32_bf16", ptr(x, torch.float32), ptr(y), x.numel(), stream())
     return y
+
+
+def cast_bf16_with_transpose(x: Tensor):
+    """fp32 [rows, cols] -> (bf16 [rows, cols], bf16 [cols, rows]) in one pass."""
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    yt = torch.empty((cols, rows), dtype=torch.bfloat16, device=x.device)
+    call("cm3p_cast_f32_bf16_t", ptr(x, torch.float32), ptr(y), ptr(yt), rows, cols, stream())
+    return y, yt
 
 
 def add_f32(a: Tensor, b: Tensor, want_bf16: bool = False, inplace: bool = True):

@@ -25,7 +25,7 @@ from transformers.utils import ModelOutput
 
 from . import kernels as K
 from .configuration_cm3p import CM3PAudioConfig, CM3PBeatmapConfig, CM3PConfig, CM3PMetadataConfig
-from .encoder import CM3PEncoder, _f32
+from .encoder import CM3PEncoder, _f32, _PadRowsFn
 
 Tensor = torch.Tensor
 
@@ -397,13 +397,13 @@ class CM3PMetadataTransformer(nn.Module):
                 raise ValueError("unpadded inputs need cu_seqlens (and max_seqlen)")
             if output_attentions:
                 raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
+            if output_pooler:  # (before the encoder runs: the reference's own message, ref:cm3p/modeling_cm3p.py:383-384)
+                raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
             _require_gpu(input_ids, "input_ids")
             h = self.encoder(input_ids=input_ids, cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, output_hidden_states=bool(output_hidden_states))
             hiddens = None
             if output_hidden_states:
                 h, hiddens = h
-            if output_pooler:
-                raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
             return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=None, hidden_states=hiddens, attentions=None)
         if output_attentions:
             raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
@@ -504,6 +504,8 @@ class CM3PBeatmapTransformer(nn.Module):
                 n = int(count.item())
                 if n != rows.shape[0]:
                     raise RuntimeError(f"shape mismatch: {n} audio placeholder tokens but {rows.shape[0]} audio embeddings")
+            if output_pooler and not self.config.cls_embed:  # before the encoder runs (ref:cm3p/modeling_cm3p.py:628-629)
+                raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
             h = self.encoder(input_ids=input_ids, position_ids=position_ids, audio_slot=slot, audio_rows=rows, cu_seqlens=cu_seqlens,
                              max_seqlen=max_seqlen, output_hidden_states=ohs)
             hiddens = None
@@ -693,11 +695,16 @@ class CM3PModel(CM3PPreTrainedModel):
                     warn_variations_stay_local()
 
         if metadata_ids is not None:
-            metadata_outputs = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
-                                                   output_attentions=output_attentions, output_hidden_states=output_hidden_states)
-            p = metadata_outputs.pooler_output
-            me = _L2NormFn.apply(_ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight))
-            metadata_embeds = me.view(*p.shape[:-1], -1)
+            try:
+                metadata_outputs = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
+                                                       output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+                p = metadata_outputs.pooler_output
+                me = _L2NormFn.apply(_ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight))
+                metadata_embeds = me.view(*p.shape[:-1], -1)
+            except BaseException:
+                if beatmap_pending is not None:  # never leave a collective un-joined behind an exception
+                    beatmap_pending.wait()
+                raise
 
         if metadata_embeds is not None and beatmap_embeds is not None:
             me2 = metadata_embeds.reshape(-1, metadata_embeds.size(-1))
@@ -739,9 +746,23 @@ class CM3PModel(CM3PPreTrainedModel):
                 # (_pad_cm3p_output, ref:cm3p/modeling_cm3p.py:999-1001) when the padded geometry was given
                 logits = lp[:, :V]
                 if indices is not None and batch_size is not None and seq_len is not None:
-                    # (detached, as the reference re-pads under no_grad when labels are given; the loss was taken on the packed rows)
-                    idx64 = indices.to(device=lp.device, dtype=torch.int64).contiguous()
-                    padded = K.scatter_rows(lp.detach().contiguous(), idx64, int(batch_size) * int(seq_len))
+                    idx64 = indices.to(device=lp.device, dtype=torch.int64).reshape(-1).contiguous()
+                    rows = int(batch_size) * int(seq_len)
+                    # the scatter kernel writes row indices[i] of a [batch_size * seq_len] buffer for every packed row i: a wrong
+                    # `indices` would be an out-of-bounds write on the GPU, not an exception - checked on the host (one read)
+                    if idx64.numel() != lp.shape[0]:
+                        raise ValueError(f"indices has {idx64.numel()} entries but there are {lp.shape[0]} unpadded rows")
+                    if idx64.numel():
+                        lo, hi = torch.stack((idx64.min(), idx64.max())).tolist()
+                        if lo < 0 or hi >= rows:
+                            raise ValueError(f"indices must lie in [0, batch_size * seq_len = {rows}); got [{lo}, {hi}]")
+                    # the reference re-pads under no_grad only when labels are given and repad_logits_with_grad is off
+                    # (ref:cm3p/modeling_cm3p.py:1000-1001); otherwise the padded logits stay differentiable
+                    keep_grad = labels is None or bool(getattr(self.config.beatmap_config, "repad_logits_with_grad", False))
+                    if keep_grad and lp.requires_grad:
+                        padded = _PadRowsFn.apply(lp, idx64, lp.shape[0], rows)
+                    else:
+                        padded = K.scatter_rows(lp.detach().contiguous(), idx64, rows)
                     logits = padded.view(int(batch_size), int(seq_len), -1)[..., :V]
             if mlm is not None:
                 if torch.is_tensor(loss):

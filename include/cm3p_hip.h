@@ -120,6 +120,10 @@ int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K);
 
 /* fp32 -> bf16 cast of n elements (n % 4 == 0): the autocast weight / activation cast in front of a bf16 linear. */
 int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+/* The same cast of a [rows, cols] matrix plus its transpose y_t [cols, rows] in one pass (identical bf16 values).  The input-gradient
+ * GEMM dx = dy W then reads W^T with the contraction index contiguous (a_kc = b_kc = 1), the faster operand form of the 256 x 256
+ * kernel - nn.Linear's autograd does the same by handing the transposed view to the BLAS.  rows, cols multiples of 8. */
+int cm3p_cast_f32_bf16_t(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream);
 /* y_f32 (and y_bf16 if not NULL) = a_f32 + b (b fp32 or bf16); n % 4 == 0.  Residual-gradient join for layer 0,
  * whose attn_norm is nn.Identity (TF:...modeling_modernbert.py:309-310). */
 int cm3p_add_f32(const float* a, const void* b, int b_dtype, float* y_f32, void* y_bf16, int64_t n, void* stream);

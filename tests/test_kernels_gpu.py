@@ -644,3 +644,26 @@ def test_gather_scatter_rows(K):
     want = torch.zeros_like(x)
     want[idx] = x[idx]
     assert torch.equal(sc, want)
+
+
+@pytest.mark.parametrize("rows,cols", [(2304, 768), (768, 1152), (72, 8), (200, 136)])
+def test_cast_with_transpose(K, rows, cols):
+    """One pass gives the bf16 copy and its transpose, both holding exactly the values of a plain cast."""
+    g = torch.Generator().manual_seed(rows + cols)
+    w = torch.randn(rows, cols, generator=g).to(DEV)
+    y, yt = K.cast_bf16_with_transpose(w)
+    assert torch.equal(y, w.to(torch.bfloat16)) and torch.equal(yt, w.to(torch.bfloat16).t().contiguous())
+
+
+@pytest.mark.parametrize("T,N,K_", [(65536, 768, 1152), (32768 + 64, 2304, 768), (512, 256, 128)])
+def test_dgrad_through_transposed_weight_equals_strided_dgrad(K, T, N, K_):
+    """dx = dy W computed from W^T (contraction index contiguous in both operands) is bit-identical to the k-strided form:
+    the same products in the same accumulation order (big shapes run gemm8p.hip, the small one the 128 x 128 kernel)."""
+    g = torch.Generator().manual_seed(T + N)
+    dy = torch.randn(T, N, generator=g).to(torch.bfloat16).to(DEV)
+    w32 = (torch.randn(N, K_, generator=g) * 0.05).to(DEV)
+    w, wt = K.cast_bf16_with_transpose(w32)
+    a, b = K.linear_dgrad(dy, w), K.linear_dgrad(dy, w, wt)
+    assert torch.equal(a, b)
+    ref = dy[:256].float() @ w.float()
+    assert (b[:256].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()

@@ -348,6 +348,43 @@ def test_caller_supplied_unpadded_inputs(name):
         model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=1, batch_size=B, seq_len=S, **extra)
 
 
+def test_caller_unpadded_mlm_logits_repad_is_validated_and_keeps_grad_like_the_reference():
+    """MLM head on caller-unpadded rows: logits come back re-padded to (B, S, V) (ref:cm3p/modeling_cm3p.py:999-1001) and equal the
+    padded run on the valid positions, zeros elsewhere; a wrong `indices` (too few entries, an entry outside batch_size * seq_len)
+    is a ValueError, not an out-of-bounds scatter on the GPU; the re-padded logits stay differentiable exactly when the
+    reference's do (labels is None or repad_logits_with_grad)."""
+    import copy
+
+    from cm3p_amd import CM3PConfig, CM3PModel
+
+    blob = load_file(os.path.join(GOLD, "d64_mlm.safetensors"))
+    inp = _inputs(blob)
+    cfg = copy.deepcopy(CASES["d64_mlm"]["cfg"])
+    cfg["beatmap_config"]["cls_embed"] = True  # (the reference has no pooling of unpadded rows without a CLS token)
+    torch.manual_seed(0)
+    model = CM3PModel(CM3PConfig(**cfg)).to(DEV)
+    ids_u, indices, cu, max_s = _unpad_like_the_reference(inp["input_ids"], inp["attention_mask"])
+    B, S = inp["input_ids"].shape
+    extra = {k: v for k, v in inp.items() if k not in ("input_ids", "attention_mask", "labels")}
+    want = model(**{k: v for k, v in inp.items() if k != "labels"}).logits.detach()
+    mask = inp["attention_mask"].bool()
+    labels_u = inp["labels"].flatten()[indices]
+    out = model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=max_s, batch_size=B, seq_len=S, labels=labels_u, **extra)
+    assert out.logits.shape == want.shape and not out.logits.requires_grad  # labels given: the reference re-pads under no_grad
+    assert _rel(out.logits[mask], want[mask]) <= 2e-3
+    assert out.logits[~mask].abs().max().item() == 0.0  # padding positions are zeros, as _pad_cm3p_output leaves them
+    out2 = model(input_ids=ids_u, indices=indices, cu_seqlens=cu, max_seqlen=max_s, batch_size=B, seq_len=S, **extra)
+    assert out2.logits.requires_grad  # labels is None: the reference re-pads with grad
+    out2.logits.float().square().mean().backward()
+    assert model.decoder.weight.grad is not None and torch.isfinite(model.decoder.weight.grad).all() and model.decoder.weight.grad.abs().sum() > 0
+    with pytest.raises(ValueError, match="indices"):
+        model(input_ids=ids_u, indices=indices[:-1], cu_seqlens=cu, max_seqlen=max_s, batch_size=B, seq_len=S, **extra)
+    bad = indices.clone()
+    bad[-1] = B * S
+    with pytest.raises(ValueError, match="indices"):
+        model(input_ids=ids_u, indices=bad, cu_seqlens=cu, max_seqlen=max_s, batch_size=B, seq_len=S, **extra)
+
+
 def test_caller_supplied_unpadded_inputs_with_mean_pooling_raise_like_the_reference():
     name = "d64_mean_pad"
     blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
