@@ -94,12 +94,18 @@ def _wgrad_splits(M: int, N: int, K: int) -> int:
     return query("cm3p_gemm_wgrad_splits", M, N, K)
 
 
+def _big_gemm_kernel(M: int, N: int) -> str:
+    """Which 256 x 256 kernel cm3p_gemm_bf16 takes for a big shape (csrc/gemm.hip big_gemm): the half-tile-ring kernel of gemm8p.hip
+    unless the extents are not multiples of 8 or CM3P_GEMM_IMPL=256 selects the r01 kernel."""
+    return "gemm8p_kernel" if (M % 8 == 0 and N % 8 == 0 and not os.environ.get("CM3P_GEMM_IMPL", "").startswith("2")) else "gemm256_kernel"
+
+
 def _gemm_tag(M: int, N: int, K: int, a_kc, b_kc, epilogue, split_k: int) -> str:
     """Profiler tag = the kernel the library will pick (same rule as cm3p_gemm_bf16 in csrc/gemm.hip), spelled like rocprof."""
     kchunk = K if split_k <= 1 else -(-(-(-K // split_k)) // 64) * 64
     big = K % 64 == 0 and kchunk % 64 == 0 and (-(-M // 256)) * (-(-N // 256)) * max(1, -(-K // kchunk)) >= 200
     b2s = lambda v: "true" if v else "false"
-    return f"{'gemm256_kernel' if big else 'gemm_bf16_kernel'}<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}>"
+    return f"{_big_gemm_kernel(M, N) if big else 'gemm_bf16_kernel'}<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}>"
 
 
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, epilogue: int,
@@ -131,7 +137,7 @@ def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_
     N = w.shape[0]
     out = _empty((T, N), torch.bfloat16, x)
     call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos, torch.float32), ptr(sin, torch.float32), S, int(per_batch), 2 * N // 3, float(q_scale), stream(),
-         tag=("gemm256_kernel" if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
+         tag=(_big_gemm_kernel(T, N) if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
          work=2.0 * T * N * Kd)
     return out
 

@@ -9,9 +9,19 @@ Shapes (BASELINE.json configs; the batch is cut to what the oracle finishes in s
       right padding so that BOTH the padded and the unpadded (varlen) executions are checked against the same oracle result
   C5  C2's shape + input_features (B, 80, 1600) with 200 audio placeholders per row (B = 2)
 
-Tolerances (bf16 GEMM / attention operands with fp32 accumulation against an all-fp32 reference):
-  loss |diff| <= 1e-3 (north star);  logits max|diff| <= 2e-2;  embeddings rel-L2 <= 2e-2;  gradients rel-L2 <= 6e-2.
+  C2 / C4 at the REAL batch (B = 32 at S = 4096, B = 16 at S = 8192), forward only: the towers are per-sample independent without
+      padding (ref:cm3p/modeling_cm3p.py:942-972), so the oracle side is B single-sample tower forwards + one contrastive head on
+      the stacked pooled vectors - the B-way softmax of the real batch feels a logit error that a 2-way softmax hides
+
+Tolerances (bf16 GEMM / attention operands with fp32 accumulation against an all-fp32 reference): loss |diff| <= 1e-3 is the north
+star and stays; every other bound is <= 3 x the error MEASURED on MI355X (TOL below; the measured values of every run are written to
+gpurun_out/parity_errors.json - or $CM3P_PARITY_JSON - and the copy committed as profiles/r03_parity_errors.json is what TOL was set
+from), so a drift of a small factor inside the old, wide bounds is no longer invisible.
 """
+import json
+import os
+import time
+
 import pytest
 import torch
 
@@ -32,6 +42,28 @@ GRAD_KEYS = [
     "metadata_projection.weight",
     "metadata_model.encoder.layers.3.mlp.Wo.weight",
 ]
+
+
+# <= 3 x measured (profiles/r03_parity_errors.json); loss: the north-star bound
+# measured maxima (r03, MI355X): loss 1.4e-4, logits 1.22e-3, embeds 1.49e-3, pooled 1.47e-3, grad 6.55e-3, hidden 2.9e-4, audio 5.26e-3
+TOL = dict(loss=1e-3, logits=3.6e-3, embeds=4.4e-3, pooled=4.4e-3, grad=1.9e-2, hidden=8.7e-4, audio=1.5e-2)
+MEASURED: dict = {}
+
+
+def _record(tag: str, key: str, value: float):
+    MEASURED.setdefault(tag, {})[key] = float(value)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_measured_errors():
+    yield
+    path = os.environ.get("CM3P_PARITY_JSON", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(dict(tolerances=TOL, measured=MEASURED), f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 def _rel(a, b):
@@ -73,14 +105,12 @@ def _check(model, batch, want, want_grads, tag):
     out.loss.backward()
     torch.cuda.synchronize()
     dl = abs(out.loss.item() - want["loss"].item())
-    assert dl <= 1e-3, f"{tag}: loss {out.loss.item():.6f} vs oracle {want['loss'].item():.6f} (|diff| {dl:.2e})"
     dlog = (out.logits_per_metadata.float().cpu() - want["logits_per_metadata"]).abs().max().item()
-    assert dlog <= 2e-2, f"{tag}: max|dlogits| {dlog:.3e}"
-    assert _rel(out.beatmap_embeds, want["beatmap_embeds"]) <= 2e-2, tag
-    assert _rel(out.metadata_embeds, want["metadata_embeds"]) <= 2e-2, tag
-    assert _rel(out.beatmap_model_output.pooler_output, want["beatmap_pooler_output"]) <= 2e-2, tag
+    errs = dict(loss=dl, logits=dlog, beatmap_embeds=_rel(out.beatmap_embeds, want["beatmap_embeds"]),
+                metadata_embeds=_rel(out.metadata_embeds, want["metadata_embeds"]),
+                beatmap_pooled=_rel(out.beatmap_model_output.pooler_output, want["beatmap_pooler_output"]))
     params = dict(model.named_parameters())
-    checked = 0
+    grad_errs = {}
     for k, g_want in want_grads.items():
         if g_want is None:
             continue
@@ -88,10 +118,69 @@ def _check(model, batch, want, want_grads, tag):
         assert g is not None and torch.isfinite(g).all(), f"{tag}: {k}"
         if g_want.norm() < 1e-12:
             continue
-        r = _rel(g, g_want)
-        assert r <= 6e-2, f"{tag}: grad {k} rel-L2 {r:.3e}"
-        checked += 1
-    return out, checked
+        grad_errs[k] = _rel(g, g_want)
+    for k, v in errs.items():
+        _record(tag, k, v)
+    for k, v in grad_errs.items():
+        _record(tag, "grad." + k, v)
+    assert dl <= TOL["loss"], f"{tag}: loss {out.loss.item():.6f} vs oracle {want['loss'].item():.6f} (|diff| {dl:.2e})"
+    assert dlog <= TOL["logits"], f"{tag}: max|dlogits| {dlog:.3e}"
+    assert errs["beatmap_embeds"] <= TOL["embeds"] and errs["metadata_embeds"] <= TOL["embeds"], (tag, errs)
+    assert errs["beatmap_pooled"] <= TOL["pooled"], (tag, errs)
+    for k, r in grad_errs.items():
+        assert r <= TOL["grad"], f"{tag}: grad {k} rel-L2 {r:.3e}"
+    return out, len(grad_errs)
+
+
+def _oracle_real_batch(sd, batch):
+    """Oracle outputs at the full batch from single-sample tower forwards (no padding: samples do not interact before the head)."""
+    from oracle import cm3p_oracle as O
+
+    cfg = O.resolve_config(CFG)
+    bp, mp = [], []
+    t0 = time.time()
+    with torch.no_grad():
+        for i in range(batch["input_ids"].shape[0]):
+            _, p, _ = O.beatmap_tower(sd, cfg["beatmap_config"], batch["input_ids"][i:i + 1], batch["attention_mask"][i:i + 1])
+            _, q = O.metadata_tower(sd, cfg["metadata_config"], batch["metadata_ids"][i:i + 1], batch["metadata_attention_mask"][i:i + 1])
+            bp.append(p)
+            mp.append(q)
+        out = O.contrastive_head(sd, torch.cat(bp), torch.cat(mp), None)
+    out["beatmap_pooler_output"] = torch.cat(bp)
+    return out, time.time() - t0
+
+
+def _check_real_batch(weights, B, S, seed, tag):
+    from oracle import cm3p_oracle as O
+
+    batch = O.synthetic_batch(CFG, B=B, S=S, L=256, seed=seed)
+    want, secs = _oracle_real_batch(weights, batch)
+    model = _hip_model(weights).eval()
+    with torch.no_grad():
+        out = model(**{k: v.to(DEV) for k, v in batch.items()})
+    torch.cuda.synchronize()
+    dl = abs(out.loss.item() - want["loss"].item())
+    dlog = (out.logits_per_metadata.float().cpu() - want["logits_per_metadata"]).abs().max().item()
+    errs = dict(loss=dl, logits=dlog, beatmap_embeds=_rel(out.beatmap_embeds, want["beatmap_embeds"]),
+                metadata_embeds=_rel(out.metadata_embeds, want["metadata_embeds"]),
+                beatmap_pooled=_rel(out.beatmap_model_output.pooler_output, want["beatmap_pooler_output"]), oracle_seconds=secs,
+                oracle_loss=want["loss"].item())
+    for k, v in errs.items():
+        _record(tag, k, v)
+    assert out.logits_per_metadata.shape == (B, B)
+    assert dl <= TOL["loss"], f"{tag}: loss {out.loss.item():.6f} vs oracle {want['loss'].item():.6f} (|diff| {dl:.2e})"
+    assert dlog <= TOL["logits"], f"{tag}: max|dlogits| {dlog:.3e}"
+    assert errs["beatmap_embeds"] <= TOL["embeds"] and errs["metadata_embeds"] <= TOL["embeds"] and errs["beatmap_pooled"] <= TOL["pooled"], (tag, errs)
+
+
+def test_c2_loss_at_the_real_batch_of_32(weights):
+    """BASELINE configs[1] AS BENCHED: B = 32 x S = 4096 / L = 256, forward; a 32-way in-batch softmax on both sides."""
+    _check_real_batch(weights, 32, 4096, 2024, "C2 B=32 forward")
+
+
+def test_c4_loss_at_the_real_batch_of_16(weights):
+    """BASELINE configs[3] AS BENCHED: B = 16 x S = 8192, forward."""
+    _check_real_batch(weights, 16, 8192, 2025, "C4 B=16 forward")
 
 
 def test_c2_shape_full_depth_forward_backward(weights):
@@ -130,7 +219,8 @@ def test_c4_shape_seq8192_padded_and_unpadded(weights):
     out_p, checked = _check(model, batch, want, grads, "C4 padded")
     assert checked >= 6
     hp = out_p.beatmap_model_output.last_hidden_state.detach().float().cpu()
-    assert _rel(hp[0, :valid], want["beatmap_last_hidden_state"][0, :valid]) <= 2e-2
+    _record("C4 padded", "hidden", _rel(hp[0, :valid], want["beatmap_last_hidden_state"][0, :valid]))
+    assert _rel(hp[0, :valid], want["beatmap_last_hidden_state"][0, :valid]) <= TOL["hidden"]
 
     model.unpad_inputs = True
     _lib.profile_begin()
@@ -139,7 +229,9 @@ def test_c4_shape_seq8192_padded_and_unpadded(weights):
     assert any("varlen" in t for t in tags), tags
     assert checked >= 6
     hu = out_u.beatmap_model_output.last_hidden_state.detach().float().cpu()
-    assert _rel(hu[0, :valid], want["beatmap_last_hidden_state"][0, :valid]) <= 2e-2
+    _record("C4 unpadded", "hidden", _rel(hu[0, :valid], want["beatmap_last_hidden_state"][0, :valid]))
+    _record("C4 unpadded", "hidden_vs_padded", _rel(hu[0, :valid], hp[0, :valid]))
+    assert _rel(hu[0, :valid], want["beatmap_last_hidden_state"][0, :valid]) <= TOL["hidden"]
     assert hu[0, valid:].abs().max().item() == 0.0  # _pad_cm3p_output zero-fills the padding rows
     assert _rel(hu[0, :valid], hp[0, :valid]) <= 5e-3
 
@@ -161,4 +253,5 @@ def test_c5_shape_audio_fused_full_depth(weights):
     assert checked >= 11
     got_audio = out.beatmap_model_output.audio_model_output.audio_embeds
     assert got_audio.shape == want["audio_embeds"].shape == (400, 768)
-    assert _rel(got_audio, want["audio_embeds"]) <= 2e-2
+    _record("C5", "audio_embeds", _rel(got_audio, want["audio_embeds"]))
+    assert _rel(got_audio, want["audio_embeds"]) <= TOL["audio"]
