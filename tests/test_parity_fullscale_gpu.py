@@ -45,8 +45,8 @@ GRAD_KEYS = [
 
 
 # <= 3 x measured (profiles/r03_parity_errors.json); loss: the north-star bound
-# measured maxima (r03, MI355X): loss 1.4e-4, logits 1.22e-3, embeds 1.49e-3, pooled 1.47e-3, grad 6.55e-3, hidden 2.9e-4, audio 5.26e-3
-TOL = dict(loss=1e-3, logits=3.6e-3, embeds=4.4e-3, pooled=4.4e-3, grad=1.9e-2, hidden=8.7e-4, audio=1.5e-2)
+# measured maxima (r03, MI355X): loss 1.4e-4, logits 2.40e-3, embeds 1.49e-3, pooled 1.47e-3, grad 6.55e-3, hidden 2.9e-4, audio 5.26e-3
+TOL = dict(loss=1e-3, logits=7e-3, embeds=4.4e-3, pooled=4.4e-3, grad=1.9e-2, hidden=8.7e-4, audio=1.5e-2)
 MEASURED: dict = {}
 
 
