@@ -24,6 +24,11 @@ Extra objects on that line:
                 so the north-star target (fraction of bf16 MFMA peak on fwd+bwd at seq 8192) is observed by the same run.
   comm          N > 1 only: the step re-timed without the gradient all-reduce (DDP no_sync) and without the embedding
                 all-gather -> exposed_allreduce_ms / exposed_allgather_ms per step (max over ranks).
+  replicas      N > 1 only: after the warm-up every rank's parameter gradients are check-summed bit for bit (int32 view, 64-bit
+                sum) and the checksums compared with one all-reduce: DDP must leave identical gradients on every rank, and the run
+                aborts (non-zero exit, rank named) if it does not; per-rank peak device memory and the attention workspace size.
+A rank that fails (process-group init, an RCCL error, a kernel error) prints `[bench] rank R: ...` and exits non-zero; the process
+group carries a timeout, so the other ranks do not wait on a barrier for ever.
 """
 from __future__ import annotations
 
@@ -238,14 +243,20 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that dies (or a collective that never completes) must end the job with an error, not hang the others on a barrier
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("CM3P_BENCH_PG_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from cm3p_amd import CM3PConfig, CM3PModel, _lib
 
+    if os.environ.get("CM3P_BENCH_INJECT_FAILURE_RANK") == str(rank):  # tests/test_bench_gpu.py: the failure contract of run()
+        raise RuntimeError("injected failure (CM3P_BENCH_INJECT_FAILURE_RANK)")
     w = dict(WORKLOADS[args.workload])
     if args.padded:
         w["padded"] = True
@@ -285,6 +296,31 @@ def main():
 
     for _ in range(args.warmup):
         step()
+
+    replicas = None
+    if world > 1:
+        # Replica consistency: after a DDP step every rank holds the SAME averaged gradients, bit for bit.
+        if args.warmup == 0:
+            step()
+        acc = torch.zeros((), dtype=torch.int64, device=device)
+        for p_ in model.parameters():
+            if p_.grad is not None:
+                acc += p_.grad.detach().contiguous().view(torch.int32).to(torch.int64).sum()
+        lo, hi = acc.clone(), acc.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        from cm3p_amd import kernels as _K
+
+        mem = torch.tensor([float(torch.cuda.max_memory_allocated(device)), float(sum(t.numel() for t in _K._fused_ws.values()))],
+                           device=device, dtype=torch.float64)
+        mems = [torch.zeros_like(mem) for _ in range(world)]
+        dist.all_gather(mems, mem)
+        replicas = {"gradient_checksum": int(acc.item()), "identical_on_all_ranks": bool(lo.item() == hi.item()),
+                    "peak_memory_gb_per_rank": [round(m[0].item() / 2 ** 30, 2) for m in mems],
+                    "attention_workspace_gb_per_rank": [round(m[1].item() / 2 ** 30, 2) for m in mems]}
+        print(f"[bench] rank {rank}: gradient checksum {int(acc.item())} peak memory {mem[0].item() / 2 ** 30:.1f} GiB", file=sys.stderr, flush=True)
+        if lo.item() != hi.item():
+            raise RuntimeError(f"replicas diverged: gradient checksums differ across ranks (min {int(lo.item())}, max {int(hi.item())})")
 
     def fence():
         torch.cuda.synchronize()
@@ -404,6 +440,8 @@ def main():
             result["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
         if comm is not None:
             result["comm"] = comm
+        if replicas is not None:
+            result["replicas"] = replicas
     if world == 1 and args.workload == "c2" and not args.no_secondary and not args.padded and not args.batch:
         # BASELINE configs[3] next to the judged number: the north-star target is quoted at seq 8192
         w4 = dict(WORKLOADS["c4"])
@@ -427,5 +465,22 @@ def main():
         dist.destroy_process_group()
 
 
+def run():
+    """main() with the failure contract of a multi-rank job: say which rank failed and exit non-zero (the launcher then tears the
+    other ranks down; the process-group timeout covers a rank that dies without a Python exception)."""
+    rank = os.environ.get("RANK", "0")
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 - report and die, whatever it was
+        import traceback
+
+        traceback.print_exc()
+        print(f"[bench] rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(3)  # no destructor may wait on a collective the other ranks will never join
+
+
 if __name__ == "__main__":
-    main()
+    run()

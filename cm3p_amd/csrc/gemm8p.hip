@@ -30,7 +30,11 @@
 
 #ifndef CM3P_G8P_ABL
 #define CM3P_G8P_ABL 0  // timing-only probes (results invalid; tools/ubench/gemm8p_ablate.sh): 1 no global stores / residual loads in the
-                        // epilogue, 2 no epilogue at all, 4 accumulators not zeroed, 8 no counted vmcnt wait in phase 4
+                        // epilogue, 2 no epilogue at all, 4 accumulators not zeroed, 8 no counted vmcnt wait in phase 4,
+                        // 16 every second workgroup of an XCD starts CM3P_G8P_DELAY x ~0.5 us late (de-phasing probe; results valid)
+#endif
+#ifndef CM3P_G8P_DELAY
+#define CM3P_G8P_DELAY 10
 #endif
 
 namespace {
@@ -199,6 +203,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
 
     f32x4 acc[8][4];
 
+    if constexpr (CM3P_G8P_ABL & 16) {
+        if ((blockIdx.x >> 3) & 1)
+            for (int i = 0; i < CM3P_G8P_DELAY * 8; ++i) __builtin_amdgcn_s_sleep(2);  // 2 x 64 cycles x 8 ~ 0.5 us per unit
+    }
     // prologue: stream k-tiles 0 (all four halves) and 1 (B-lo, A-lo, B-hi); A-hi of k-tile 1 follows in phase 1 of k-tile 0
     stream_setup(sv);
     oa.template stage<slot_off(0, kAL)>(0, ldsw);

@@ -48,3 +48,35 @@ def test_bench_two_ranks_share_the_card_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"].startswith("dp2")
     assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]  # whole-job pairs/s
     assert "cpu_baseline" not in d  # (rank 0 at N = 1 only)
+    r = d["replicas"]  # every rank holds bit-identical gradients after a DDP step; memory is reported per rank
+    assert r["identical_on_all_ranks"] is True and len(r["peak_memory_gb_per_rank"]) == 2 and min(r["peak_memory_gb_per_rank"]) > 0
+    assert d["comm"]["gradient_bytes_per_step"] > 0
+
+
+def _torchrun(n, extra_env, *args, port="29543"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *args],
+                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+
+
+def test_bench_names_the_failing_rank_and_exits_non_zero():
+    """A rank that fails must end the job with an error that names it - not leave the other ranks on a barrier."""
+    p = _torchrun(2, dict(CM3P_BENCH_BACKEND="gloo", CM3P_BENCH_INJECT_FAILURE_RANK="1", CM3P_BENCH_PG_TIMEOUT_S="60"),
+                  "--steps", "1", "--warmup", "1", "--batch", "2", "--no-optimizer", port="29545")
+    assert p.returncode != 0
+    assert "[bench] rank 1: RuntimeError: injected failure" in p.stderr, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]  # no result line from a failed job
+
+
+def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """First contact of the N > 1 path with RCCL: one rank per GPU, exactly as the driver launches it.  Skipped on a one-GPU box."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    p = _torchrun(2, {}, "--steps", "2", "--warmup", "1", "--batch", "4", "--no-optimizer", port="29547")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["replicas"]["identical_on_all_ranks"] is True
+    assert d["comm"]["exposed_allreduce_ms"] is not None

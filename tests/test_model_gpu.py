@@ -42,7 +42,7 @@ def _build(name, dtype=torch.float32):
 
 
 def _inputs(blob):
-    return {k[3:]: v.to(DEV) for k, v in blob.items() if k.startswith("in.")}
+    return {k[3:]: v.to("cuda") for k, v in blob.items() if k.startswith("in.")}  # the CURRENT device (multi-GPU tests set it per rank)
 
 
 @pytest.mark.parametrize("name", GPU_CASES)
@@ -208,20 +208,24 @@ def test_gather_negatives_world_size_one_equals_local_loss():
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, name, out):
+def _two_rank_worker(rank, world, port, name, out, backend="gloo"):
+    import datetime
+
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU of the test box
+    dev = rank if backend == "nccl" else 0  # gloo: two ranks share the one GPU of the test box; nccl (RCCL): one GPU per rank
+    torch.cuda.set_device(dev)
+    kw = dict(device_id=torch.device("cuda", dev)) if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
     try:
-        torch.cuda.set_device(0)
         blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
         model = _build(name)
         model.gather_negatives = True
         for p in model.beatmap_model.audio_encoder.parameters():
             p.requires_grad_(False)  # no input_features in this case: DDP needs every trainable parameter to get a gradient
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev])
         full = _inputs(blob)
         b = full["input_ids"].shape[0] // world
         part = {k: v[rank * b:(rank + 1) * b].contiguous() for k, v in full.items()}
@@ -234,20 +238,26 @@ def _two_rank_worker(rank, world, port, name, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_gathered_step_equals_single_process_global_batch():
-    """SURVEY §8e on the real kernels: 2 ranks (gloo, sharing cuda:0), DDP gradient averaging + all-gathered negatives
-    == one process on the concatenated batch.  Tolerance: bf16 re-rounding between the two decompositions (1e-2)."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_gathered_step_equals_single_process_global_batch(backend):
+    """SURVEY §8e on the real kernels: 2 ranks, DDP gradient averaging + all-gathered negatives (the async gather started under
+    the metadata tower, its reduce-scatter backward) == one process on the concatenated batch.  gloo: both ranks share cuda:0
+    (runs on every box); nccl: RCCL with one GPU per rank - skipped unless the box has two GPUs, so the first multi-GPU box that
+    runs the suite exercises RCCL at N > 1 before the scaling bench does.
+    Tolerance: bf16 re-rounding between the two decompositions (1e-2)."""
     import socket
 
     import torch.multiprocessing as mp
 
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
     name = "d64_cls_nopad"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(2, port, name, out), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, name, out, backend), nprocs=2, join=True)
 
     blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
     model = _build(name)
