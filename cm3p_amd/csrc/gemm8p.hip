@@ -343,11 +343,17 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                 G8P_LANE_XCHG_FENCE();
                 if (rotate) {
                     // rotary embedding at store time on the bf16-rounded projection (what the reference's autocast path computes):
-                    // a lane takes (row, dims d..d+7 and d+32..d+39) of the wave's head; one table read serves both chunks
+                    // a lane takes (row, dims d..d+7 and d+32..d+39) of the wave's head - one table read serves both chunks - and
+                    // writes the rotated pair back IN PLACE (each chunk of the staged rows belongs to exactly one lane); the rows
+                    // then leave through the common path below as whole 128-byte lines.  (Storing the two chunks straight from
+                    // here left two half-line stores per row and the L2 fetched every half-written line: 1.6 GB of traffic for
+                    // 0.8 GB, r03 PMC; rotating every pair twice so that a lane owns one chunk doubled the exposed VALU work and
+                    // was slower still.)
                     const int row = lane >> 2, dc = lane & 3;
-                    const u32x4 xa = *reinterpret_cast<const u32x4*>(eb + row * 128 + ((dc ^ (row & 7)) << 4));
-                    const u32x4 xb = *reinterpret_cast<const u32x4*>(eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4));
-                    G8P_LANE_XCHG_FENCE();
+                    char* pa = eb + row * 128 + ((dc ^ (row & 7)) << 4);
+                    char* pb = eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4);
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(pa);
+                    const u32x4 xb = *reinterpret_cast<const u32x4*>(pb);
                     if (FULL || mw + i4 * 16 + row < M) {
                         int64_t prow;
                         if (rope.per_batch) prow = mw + i4 * 16 + row;
@@ -361,21 +367,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                         const float* sr = rope.sin + prow * 32 + dc * 8;
                         const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
-                        const uint32_t wa[4] = {xa.x, xa.y, xa.z, xa.w}, wb[4] = {xb.x, xb.y, xb.z, xb.w};
                         const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                         const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                        uint32_t oa[4], ob[4];
+                        u32x4 oa, ob;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const float a0 = bf16lo(wa[t]), a1 = bf16hi(wa[t]), b0 = bf16lo(wb[t]), b1 = bf16hi(wb[t]);
+                            const float a0 = bf16lo(xa[t]), a1 = bf16hi(xa[t]), b0 = bf16lo(xb[t]), b1 = bf16hi(xb[t]);
                             oa[t] = pack_bf16x2(qs * (a0 * cs[2 * t] - b0 * sn[2 * t]), qs * (a1 * cs[2 * t + 1] - b1 * sn[2 * t + 1]));
                             ob[t] = pack_bf16x2(qs * (b0 * cs[2 * t] + a0 * sn[2 * t]), qs * (b1 * cs[2 * t + 1] + a1 * sn[2 * t + 1]));
                         }
-                        char* dst = Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16;
-                        G8P_GLOBAL(*reinterpret_cast<u32x4*>(dst) = (u32x4{oa[0], oa[1], oa[2], oa[3]}));
-                        G8P_GLOBAL(*reinterpret_cast<u32x4*>(dst + 64) = (u32x4{ob[0], ob[1], ob[2], ob[3]}));
+                        *reinterpret_cast<u32x4*>(pa) = oa;
+                        *reinterpret_cast<u32x4*>(pb) = ob;
                     }
-                } else {
+                    G8P_LANE_XCHG_FENCE();
+                }
+                {
                     const int r0 = lane >> 3, r1 = 8 + (lane >> 3), ch = lane & 7;
                     const u32x4 x0 = *reinterpret_cast<const u32x4*>(eb + r0 * 128 + ((ch ^ (r0 & 7)) << 4));
                     const u32x4 x1 = *reinterpret_cast<const u32x4*>(eb + r1 * 128 + ((ch ^ (r1 & 7)) << 4));
