@@ -620,6 +620,58 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// output_attentions: the probabilities themselves, [B, nh, S, S] fp32 - what the reference returns when a caller asks for
+// attention weights (TF then runs eager_attention_forward, TF:models/modernbert/modeling_modernbert.py:133-170: softmax of
+// scale * q k^T + additive mask in fp32).  An inspection path, not a hot one: p[q, k] = exp(scale * q.k - lse[q]) from the lse the
+// forward stored, plain fp32 FMAs, 64 x 64 tiles.  Invisible keys give exact zeros; a row with no visible key is uniform
+// 1 / S, as the eager path's finite additive mask (finfo.min on every key) leaves it.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_probs_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ lse,
+                                                         const uint8_t* __restrict__ kmask, float* __restrict__ probs, int S, int nh,
+                                                         int window, float q_mul) {
+    __shared__ float ks[64][65];
+    const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int qrow = qb * 64 + (tid >> 2), part = tid & 3;
+    const int64_t ld = (int64_t)3 * nh * 64;
+    const uint16_t* base = qkv + (int64_t)b * S * ld + head * 64;
+    float q[64];
+    const int qc = min(qrow, S - 1);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)qc * ld + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[8 * c + j] = (float)v[j] * q_mul;  // q_mul: log2(e) * scale for plain q, 1 when q is prescaled
+    }
+    const float l = lse[((int64_t)b * nh + head) * S + qc];
+    const bool dead = l == __builtin_huge_valf();
+    const float l2 = l * kLog2e;
+    float* prow = probs + (((int64_t)b * nh + head) * S + qc) * S;
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 8; i += 256) {
+            const int r = i >> 3, c = i & 7, kr = min(k0 + r, S - 1);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + nh * 64 + (int64_t)kr * ld + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ks[r][8 * c + j] = (float)v[j];
+        }
+        __syncthreads();
+        if (qrow < S) {
+#pragma unroll 4
+            for (int kk = 0; kk < 16; ++kk) {
+                const int kl = part * 16 + kk, key = k0 + kl;
+                if (key >= S) break;
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 64; ++d) acc = __builtin_fmaf(q[d], ks[kl][d], acc);
+                const bool vis = (kmask == nullptr || kmask[(int64_t)b * S + key] != 0) && (window < 0 || abs(qrow - key) <= window);
+                prow[key] = dead ? 1.0f / (float)S : (vis ? __builtin_amdgcn_exp2f(acc - l2) : 0.f);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
@@ -740,6 +792,15 @@ int cm3p_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, con
     const int rc = launch_attn_bwd(qkv, out, dout, lse, delta, dqkv, nullptr, B, max_seqlen, nh, window, scale, cos_tab, sin_tab, 0,
                                    VarLen{cu_seqlens, total}, stages, q_prescaled != 0, static_cast<hipStream_t>(stream));
     if (rc != CM3P_OK) return rc;
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, float* probs, int B, int S, int nh, int window, float scale,
+                    int q_prescaled, void* stream) {
+    CM3P_REQUIRE(qkv && lse && probs && B > 0 && S > 0 && nh > 0 && scale > 0.f && cm3p_aligned16(qkv));
+    attn_probs_kernel<<<dim3((S + 63) / 64, nh, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(qkv), lse, key_mask, probs, S, nh, window, q_prescaled ? 1.0f : scale * kLog2e);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -106,7 +106,7 @@ class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
     __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint",
-                 "handoff")
+                 "handoff", "attn_out")
 
 
 def _hand_upstream(geo: _Geometry, gx32: Tensor, gx16: Optional[Tensor]) -> None:
@@ -147,6 +147,8 @@ def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
         o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, prescaled=True)
     else:
         o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True)
+        if geo.attn_out is not None and len(geo.attn_out) == i:  # output_attentions (not again when a checkpointed layer is recomputed)
+            geo.attn_out.append(K.attn_probs(qkv, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True))
     x_mid = K.linear_fwd(o, Wo_b, resid=x)
     _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
     h = K.linear_fwd(xn2, Wi_b)
@@ -372,9 +374,12 @@ class CM3PEncoder(nn.Module):
     def forward(self, input_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 position_ids: Optional[Tensor] = None, inputs_embeds: Optional[Tensor] = None,
                 audio_slot: Optional[Tensor] = None, audio_rows: Optional[Tensor] = None, unpad: bool = False,
-                output_hidden_states: bool = False, cu_seqlens: Optional[Tensor] = None, max_seqlen: Optional[int] = None):
+                output_hidden_states: bool = False, cu_seqlens: Optional[Tensor] = None, max_seqlen: Optional[int] = None,
+                output_attentions: bool = False):
         """-> last_hidden_state (B, S, H) fp32 [, tuple of L+1 detached hidden states (the stack's input and every layer's output,
         TF:...modeling_modernbert.py:457-470) when output_hidden_states].  Exactly one of input_ids / inputs_embeds.
+        output_attentions: -> (last_hidden_state, hidden states or None, tuple of L attention-probability tensors (B, nh, S, S) fp32,
+        detached): what the reference returns as `attentions` (TF runs its eager attention for such a call); padded execution only.
 
         unpad: run the stack on the valid tokens only, packed back to back (what the reference's flash_attention_2 path does,
         ref:cm3p/modeling_cm3p.py:911-931); padding positions of the result are zero.  Used when the mask is a right-padded
@@ -383,7 +388,11 @@ class CM3PEncoder(nn.Module):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         if cu_seqlens is not None:
+            if output_attentions:
+                raise NotImplementedError("output_attentions with unpadded inputs: attention probabilities are (B, nh, S, S) tensors of a padded batch")
             return self._forward_prepacked(input_ids, position_ids, audio_slot, audio_rows, cu_seqlens, max_seqlen, output_hidden_states)
+        if output_attentions:
+            unpad = False  # the probabilities are laid out per padded (batch, head, query, key)
         if input_ids is not None and input_ids.dtype != torch.int64:
             input_ids = input_ids.to(torch.int64)  # nn.Embedding takes IntTensor or LongTensor; the kernels index with int64
         ref = input_ids if input_ids is not None else inputs_embeds
@@ -417,7 +426,7 @@ class CM3PEncoder(nn.Module):
         else:
             x0 = _LayerNormFn.apply(inputs_embeds.reshape(B * S, H), self.embeddings.norm.weight, cfg.norm_eps)
 
-        y, hiddens = self._run_stack(x0, B, S, attention_mask, position_ids, packed, output_hidden_states, dev)
+        y, hiddens, attns = self._run_stack(x0, B, S, attention_mask, position_ids, packed, output_hidden_states, dev, output_attentions)
         if hiddens is not None:
             if packed is not None:
                 hiddens = [K.scatter_rows(h[:n_valid].contiguous(), idx, B * S) for h in hiddens]
@@ -425,9 +434,12 @@ class CM3PEncoder(nn.Module):
         if packed is not None:
             y = _PadRowsFn.apply(y, idx, n_valid, B * S)
         y = y.view(B, S, H)
+        if output_attentions:
+            return y, hiddens, attns
         return (y, hiddens) if output_hidden_states else y
 
-    def _run_stack(self, x0: Tensor, B: int, S: int, attention_mask, position_ids, packed, output_hidden_states: bool, dev):
+    def _run_stack(self, x0: Tensor, B: int, S: int, attention_mask, position_ids, packed, output_hidden_states: bool, dev,
+                   output_attentions: bool = False):
         """The L encoder layers + final norm on [rows, H]; `packed` = (idx, cu, max_s, n_valid, n_rows, pos) for unpadded execution."""
         cfg = self.config
         H = cfg.hidden_size
@@ -465,6 +477,7 @@ class CM3PEncoder(nn.Module):
         geo.save = torch.is_grad_enabled() and (x0.requires_grad or self.final_norm.weight.requires_grad
                                                 or any(w.requires_grad for ws in weights for w in ws))
         geo.handoff = None
+        geo.attn_out = [] if output_attentions else None
         # output_hidden_states: the stack's input and every layer's output (TF:...modeling_modernbert.py:457-470), detached
         hiddens = [x0.detach()] if output_hidden_states else None
         x = x0
@@ -473,7 +486,9 @@ class CM3PEncoder(nn.Module):
             if hiddens is not None:
                 hiddens.append(x.detach())
         y = _FinalNormFn.apply(geo, x, self.final_norm.weight)
-        return y, hiddens
+        attns = tuple(geo.attn_out) if geo.attn_out is not None else None
+        geo.attn_out = None
+        return y, hiddens, attns
 
     def _forward_prepacked(self, input_ids: Tensor, position_ids: Optional[Tensor], audio_slot, audio_rows, cu_seqlens: Tensor,
                            max_seqlen: Optional[int], output_hidden_states: bool):
@@ -517,7 +532,7 @@ class CM3PEncoder(nn.Module):
         x0 = _EmbedLNFn.apply(ids, self.embeddings.tok_embeddings.weight, self.embeddings.norm.weight, cfg.norm_eps,
                               -1 if pad is None else pad, None if slot_p is None else slot_p.contiguous(), audio_rows)
         packed = (None, cu, max(max_s, n_rows - total), total, n_rows, pos.contiguous())
-        y, hiddens = self._run_stack(x0, cu.numel() - 1, max_s, None, None, packed, output_hidden_states, dev)
+        y, hiddens, _ = self._run_stack(x0, cu.numel() - 1, max_s, None, None, packed, output_hidden_states, dev)
         if n_rows != total:
             y = y[:total]
             if hiddens is not None:

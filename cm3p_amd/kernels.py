@@ -206,6 +206,13 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
     return out, lse
 
 
+def attn_probs(qkv: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float, prescaled: bool = False) -> Tensor:
+    """output_attentions: the probabilities [B, nh, S, S] fp32 of one layer, from qkv and the lse attn_fwd stored (inspection path)."""
+    probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=qkv.device)
+    call("cm3p_attn_probs", ptr(qkv), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), ptr(probs), B, S, nh, window, scale, int(prescaled), stream())
+    return probs
+
+
 ATTN_BWD_DQ, ATTN_BWD_DKV = 1, 2  # stages of cm3p_attn_bwd (include/cm3p_hip.h)
 
 

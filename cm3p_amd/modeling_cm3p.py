@@ -396,7 +396,7 @@ class CM3PMetadataTransformer(nn.Module):
             if cu_seqlens is None:
                 raise ValueError("unpadded inputs need cu_seqlens (and max_seqlen)")
             if output_attentions:
-                raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
+                raise NotImplementedError("output_attentions with unpadded inputs: attention probabilities are (B, nh, S, S) tensors of a padded batch")
             if output_pooler:  # (before the encoder runs: the reference's own message, ref:cm3p/modeling_cm3p.py:383-384)
                 raise NotImplementedError("Pooling with unpadded input is not implemented yet.")
             _require_gpu(input_ids, "input_ids")
@@ -405,8 +405,6 @@ class CM3PMetadataTransformer(nn.Module):
             if output_hidden_states:
                 h, hiddens = h
             return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=None, hidden_states=hiddens, attentions=None)
-        if output_attentions:
-            raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         _require_gpu(input_ids, "input_ids")
         is_3d = input_ids.dim() == 3
         B0 = input_ids.size(0)
@@ -414,9 +412,14 @@ class CM3PMetadataTransformer(nn.Module):
         if is_3d:  # (B, V, L) -> (B*V, L), ref:cm3p/modeling_cm3p.py:351-357
             ids2 = input_ids.reshape(-1, input_ids.size(-1))
             am2 = attention_mask.reshape(-1, attention_mask.size(-1)) if attention_mask is not None else None
-        h = self.encoder(input_ids=ids2, attention_mask=am2, output_hidden_states=bool(output_hidden_states))
-        hiddens = None
-        if output_hidden_states:
+        # output_attentions: the probabilities of every layer, (B[*V], nh, L, L) fp32 (a separate inspection kernel: the flash
+        # kernels never materialise them; the reference switches to eager attention for such a call)
+        h = self.encoder(input_ids=ids2, attention_mask=am2, output_hidden_states=bool(output_hidden_states),
+                         output_attentions=bool(output_attentions))
+        hiddens = attns = None
+        if output_attentions:
+            h, hiddens, attns = h
+        elif output_hidden_states:
             h, hiddens = h
         pooled = _PoolFn.apply(h, am2, bool(self.config.cls_embed)) if output_pooler else None
         if is_3d:
@@ -425,7 +428,7 @@ class CM3PMetadataTransformer(nn.Module):
                 pooled = pooled.view(B0, -1, pooled.size(-1))
             if hiddens is not None:
                 hiddens = tuple(t.view(B0, -1, t.size(-2), t.size(-1)) for t in hiddens)
-        return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=None)
+        return BaseModelOutputWithPooling(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=attns)
 
 
 class CM3PMultiModalProjector(nn.Module):
@@ -457,10 +460,14 @@ class CM3PAudioEncoder(nn.Module):
         x = audio_frontend(input_features, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)  # (B, T/2, H)
         B, T2, _ = x.shape
         pos = torch.arange(T2, device=x.device).unsqueeze(0).repeat(B, 1)  # explicit per-row positions, :506-507
-        h = self.encoder(inputs_embeds=x, position_ids=pos)
+        attns = None
+        if output_attentions:
+            h, _, attns = self.encoder(inputs_embeds=x, position_ids=pos, output_attentions=True)
+        else:
+            h = self.encoder(inputs_embeds=x, position_ids=pos)
         audio_embeds = audio_projector(h.reshape(-1, self.config.projector_intermediate_size),
                                        self.multi_modal_projector.linear_1.weight, self.multi_modal_projector.linear_2.weight)
-        return CM3PAudioModelOutput(audio_embeds=audio_embeds, last_hidden_state=h, hidden_states=None, attentions=None)
+        return CM3PAudioModelOutput(audio_embeds=audio_embeds, last_hidden_state=h, hidden_states=None, attentions=attns)
 
 
 class CM3PBeatmapTransformer(nn.Module):
@@ -483,10 +490,11 @@ class CM3PBeatmapTransformer(nn.Module):
                 attention_mask: Optional[Tensor] = None, sliding_window_mask=None, position_ids: Optional[Tensor] = None,
                 inputs_embeds: Optional[Tensor] = None, indices=None, cu_seqlens=None, max_seqlen=None, batch_size=None,
                 seq_len=None, output_attentions=None, output_hidden_states=None, output_pooler: bool = True) -> CM3PBeatmapModelOutput:
-        if output_attentions:
-            raise NotImplementedError("output_attentions: the flash kernels never materialise attention probabilities")
         audio_out = None
         ohs = bool(output_hidden_states)
+        oat = bool(output_attentions)
+        if oat and (indices is not None or cu_seqlens is not None):
+            raise NotImplementedError("output_attentions with unpadded inputs: attention probabilities are (B, nh, S, S) tensors of a padded batch")
         if indices is not None or cu_seqlens is not None:
             # Caller-supplied unpadded rows (ref:cm3p/modeling_cm3p.py:911-931 with indices / cu_seqlens / max_seqlen given, layout of
             # _unpad_cm3p_input :65-104): input_ids (total_nnz,), last_hidden_state stays (total_nnz, H), CLS pooling reads row
@@ -524,7 +532,7 @@ class CM3PBeatmapTransformer(nn.Module):
                 raise NotImplementedError("input_features together with inputs_embeds is not supported")
             _require_gpu(inputs_embeds, "inputs_embeds")
             h = self.encoder(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids,
-                             output_hidden_states=ohs)
+                             output_hidden_states=ohs, output_attentions=oat)
         else:
             _require_gpu(input_ids, "input_ids")
             slot = rows = None
@@ -541,12 +549,14 @@ class CM3PBeatmapTransformer(nn.Module):
             unpad = self.unpad_inputs if self.unpad_inputs is not None else \
                 getattr(self.config, "_attn_implementation", None) == "flash_attention_2"
             h = self.encoder(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, audio_slot=slot,
-                             audio_rows=rows, unpad=bool(unpad), output_hidden_states=ohs)
-        hiddens = None
-        if ohs:
+                             audio_rows=rows, unpad=bool(unpad), output_hidden_states=ohs, output_attentions=oat)
+        hiddens = attns = None
+        if oat:
+            h, hiddens, attns = h
+        elif ohs:
             h, hiddens = h
         pooled = _PoolFn.apply(h, attention_mask, bool(self.config.cls_embed)) if output_pooler else None
-        return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=None,
+        return CM3PBeatmapModelOutput(last_hidden_state=h, pooler_output=pooled, hidden_states=hiddens, attentions=attns,
                                       audio_model_output=audio_out)
 
 
@@ -800,7 +810,7 @@ class CM3PMetadataModelWithProjection(CM3PPreTrainedModel):
         p = out.pooler_output
         emb = _ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight).view(*p.shape[:-1], -1)
         return CM3PMetadataModelOutput(metadata_embeds=emb, last_hidden_state=out.last_hidden_state, hidden_states=out.hidden_states,
-                                       attentions=None)
+                                       attentions=out.attentions)
 
 
 class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
@@ -828,7 +838,7 @@ class CM3PBeatmapModelWithProjection(CM3PPreTrainedModel):
                                  output_hidden_states=output_hidden_states)
         emb = _ProjectFn.apply(out.pooler_output, self.beatmap_projection.weight)
         return CM3PBeatmapModelOutput(beatmap_embeds=emb, pooler_output=out.pooler_output, last_hidden_state=out.last_hidden_state,
-                                      hidden_states=out.hidden_states, attentions=None, audio_model_output=out.audio_model_output)
+                                      hidden_states=out.hidden_states, attentions=out.attentions, audio_model_output=out.audio_model_output)
 
 
 class _TakeRowsFn(torch.autograd.Function):
@@ -896,7 +906,7 @@ class CM3PForMaskedLM(CM3PPreTrainedModel):
         else:
             lp = _MLMHeadFn.apply(*head_args)
         logits = lp[..., :V] if sparse else lp.view(Bq, Sq, -1)[..., :V]
-        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=None)
+        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=out.attentions)
 
 
 class _AddBiasFn(torch.autograd.Function):
@@ -980,7 +990,7 @@ class CM3PForBeatmapClassification(CM3PPreTrainedModel):
                 loss = _CrossEntropySumFn.apply(spec, logits)
             else:
                 loss = _PointwiseLossFn.apply(logits.reshape(-1), labels.reshape(-1), 1)
-        return BeatmapClassifierOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=None)
+        return BeatmapClassifierOutput(loss=loss, logits=logits, hidden_states=out.hidden_states, attentions=out.attentions)
 
 
 

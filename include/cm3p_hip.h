@@ -158,6 +158,14 @@ int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B
  * extra multiply per score) - q is never re-rounded to bf16 either way.  `scale` is always the softmax scale (1 / sqrt(64)). */
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                   float scale, int q_prescaled, void* stream);
+
+/* output_attentions: the attention probabilities [B, nh, S, S] fp32 of one layer from qkv and the lse cm3p_attn_fwd stored - what
+ * the reference returns as `attentions` (TF switches to eager_attention_forward for such a call,
+ * TF:models/modernbert/modeling_modernbert.py:133-170).  An inspection path (plain fp32 arithmetic, B * nh * S * S * 4 bytes of
+ * output).  Invisible keys: exact zeros; a row with no visible key: uniform 1 / S, as the eager path's finite additive mask leaves it.
+ * Padded layout only. */
+int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, float* probs, int B, int S, int nh, int window, float scale,
+                    int q_prescaled, void* stream);
 /* Backward.  delta: [B, nh, S] fp32 workspace.  dqkv: [B, S, 3, nh, 64] bf16, fully overwritten.
  * If cos_tab/sin_tab are not NULL the inverse rotary rotation is applied to dq and dk before they are stored (the
  * backward of apply_rotary_pos_emb), with pos_batch_stride = 0 (one position row for all batches) or S.

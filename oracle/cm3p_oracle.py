@@ -143,7 +143,17 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, allowed: Optional[Tensor], scale: floa
     return p @ v
 
 
-def encoder_layer(x: Tensor, sd: dict, prefix: str, i: int, cfg: dict, cos_sin, allowed, eager: bool) -> Tensor:
+def eager_attention_probs(q: Tensor, k: Tensor, allowed: Optional[Tensor], scale: float) -> Tensor:
+    """What `output_attentions=True` returns per layer: TF then runs eager_attention_forward
+    (TF:models/modernbert/modeling_modernbert.py:133-170): softmax(scale * q k^T + additive mask, fp32).  The additive mask is
+    finfo.min (finite) on the invisible keys, so a row with no visible key comes out uniform over ALL keys, not NaN."""
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if allowed is not None:
+        s = s + torch.where(allowed, 0.0, torch.finfo(torch.float32).min)
+    return torch.softmax(s, dim=-1)
+
+
+def encoder_layer(x: Tensor, sd: dict, prefix: str, i: int, cfg: dict, cos_sin, allowed, eager: bool, attn_out: Optional[list] = None) -> Tensor:
     """ModernBertEncoderLayer.forward (TF:...modeling_modernbert.py:318-333) with attention :262-301, MLP :89-91."""
     nh = cfg["num_attention_heads"]
     H = cfg["hidden_size"]
@@ -156,6 +166,8 @@ def encoder_layer(x: Tensor, sd: dict, prefix: str, i: int, cfg: dict, cos_sin, 
     qkv = F.linear(h, sd[p + "attn.Wqkv.weight"]).view(B, S, 3, nh, d)
     q, k, v = (t.transpose(1, 2) for t in qkv.unbind(dim=2))
     q, k = apply_rope(q, k, *cos_sin)
+    if attn_out is not None:
+        attn_out.append(eager_attention_probs(q, k, allowed, d ** -0.5))
     a = sdpa(q, k, v, allowed, d ** -0.5, eager).transpose(1, 2).reshape(B, S, H)
     x = x + F.linear(a, sd[p + "attn.Wo.weight"])
 
@@ -167,8 +179,10 @@ def encoder_layer(x: Tensor, sd: dict, prefix: str, i: int, cfg: dict, cos_sin, 
 
 def encoder(sd: dict, prefix: str, cfg: dict, *, input_ids: Optional[Tensor] = None,
             inputs_embeds: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
-            position_ids: Optional[Tensor] = None, eager: bool = False, collect: Optional[list] = None) -> Tensor:
-    """ModernBertModel.forward (TF:...modeling_modernbert.py:434-478)."""
+            position_ids: Optional[Tensor] = None, eager: bool = False, collect: Optional[list] = None,
+            attn_out: Optional[list] = None) -> Tensor:
+    """ModernBertModel.forward (TF:...modeling_modernbert.py:434-478).  attn_out: receives every layer's eager attention
+    probabilities (B, nh, S, S) - the `attentions` of an output_attentions=True call."""
     if inputs_embeds is None:
         inputs_embeds = F.embedding(input_ids, sd[prefix + "embeddings.tok_embeddings.weight"])
     B, S, H = inputs_embeds.shape
@@ -186,7 +200,7 @@ def encoder(sd: dict, prefix: str, cfg: dict, *, input_ids: Optional[Tensor] = N
     }
     for i in range(cfg["num_hidden_layers"]):
         g = layer_is_global(cfg, i)
-        x = encoder_layer(x, sd, prefix, i, cfg, tuple(t.to(x.dtype) for t in rope[g]), masks[g], eager)
+        x = encoder_layer(x, sd, prefix, i, cfg, tuple(t.to(x.dtype) for t in rope[g]), masks[g], eager, attn_out)
         if collect is not None:
             collect.append(x)
     return layer_norm(x, sd[prefix + "final_norm.weight"], cfg["norm_eps"])

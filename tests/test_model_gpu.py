@@ -846,3 +846,43 @@ def test_default_config_full_length_properties():
     e_u = embeds(ids_c, mask_c, unpad=True)
     assert _rel(e_u, e_c) <= 5e-3  # packed vs padded execution (different tile alignment for row 1 only)
     assert torch.equal(e_u[0], e_c[0])  # row 0 starts at packed row 0: same tiles, same bits
+
+
+def test_output_attentions_matches_the_reference_eager_probabilities():
+    """output_attentions=True: every tower returns L tensors (B, nh, S, S) fp32 = softmax(scale q k^T + mask) as the reference's
+    eager path computes them (oracle: eager_attention_probs) - global and sliding-window layers, key padding (exact zeros on
+    invisible keys), a padded query row whose window holds no valid key (uniform 1 / S, the finite additive mask's result),
+    rows summing to one; the other outputs are unchanged by the flag."""
+    from oracle import cm3p_oracle as O
+
+    name = "d64_mean_longpad"  # right padding long enough that local-attention queries in the padding see no key at all
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    inp = _inputs(blob)
+    model = _build(name).eval()
+    with torch.no_grad():
+        ref_out = model(**inp)
+        out = model(**inp, output_attentions=True)
+    assert torch.equal(out.logits_per_metadata, ref_out.logits_per_metadata)
+    cfg = O.resolve_config(CASES[name]["cfg"])
+    sd = {k: v.float() for k, v in model.state_dict().items()}
+    for tower, prefix, c, ids, mask, got in (
+            ("beatmap", "beatmap_model.encoder.", cfg["beatmap_config"], inp["input_ids"], inp["attention_mask"], out.beatmap_model_output.attentions),
+            ("metadata", "metadata_model.encoder.", cfg["metadata_config"], inp["metadata_ids"], inp["metadata_attention_mask"], out.metadata_model_output.attentions)):
+        want = []
+        O.encoder({k: v.cpu() for k, v in sd.items()}, prefix, c, input_ids=ids.cpu(), attention_mask=mask.cpu(), attn_out=want)
+        assert len(got) == c["num_hidden_layers"] == len(want)
+        B, S = ids.shape
+        saw_dead = False
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.shape == (B, c["num_attention_heads"], S, S) and g.dtype == torch.float32 and not g.requires_grad
+            g = g.cpu()
+            assert (g - w).abs().max().item() <= 3e-3, (tower, i, (g - w).abs().max().item())  # bf16 q / k against an fp32 reference
+            assert (g.sum(-1) - 1).abs().max().item() <= 2e-3
+            invisible = w == 0
+            assert (g[invisible] == 0).all()  # masked keys: exact zeros
+            dead = (w - 1.0 / S).abs().max(-1).values < 1e-9
+            if dead.any():
+                saw_dead = True
+                assert (g[dead] - 1.0 / S).abs().max().item() < 1e-7
+        if tower == "beatmap":
+            assert saw_dead  # the fixture exists for this edge case
