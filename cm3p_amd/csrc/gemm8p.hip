@@ -24,6 +24,8 @@
 //   WAR  a slot is restaged >= 2 phases after its last ds_read (A-lo: read p1, restaged p3; B-hi: p2 -> p4; A-hi: p3 -> p1 of the
 //        next k-tile), except B-lo (read p1, restaged p2): its four reads are issued first and retired by `lgkmcnt(8)` before the
 //        first barrier of p1.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -31,7 +33,9 @@
 #ifndef CM3P_G8P_ABL
 #define CM3P_G8P_ABL 0  // timing-only probes (results invalid; tools/ubench/gemm8p_ablate.sh): 1 no global stores / residual loads in the
                         // epilogue, 2 no epilogue at all, 4 accumulators not zeroed, 8 no counted vmcnt wait in phase 4,
-                        // 16 every second workgroup of an XCD starts CM3P_G8P_DELAY x ~0.5 us late (de-phasing probe; results valid)
+                        // 16 every second workgroup of an XCD starts CM3P_G8P_DELAY x ~0.5 us late (de-phasing probe; results valid),
+                        // 32 no B-lo fragment reads in phase 1 (stale registers: what moving them out of the longest phase could buy),
+                        // 64 no LDS-DMA in the k-loop (stale tiles: the cost of issuing the operand stream)
 #endif
 #ifndef CM3P_G8P_DELAY
 #define CM3P_G8P_DELAY 10
@@ -49,6 +53,10 @@ __host__ __device__ constexpr int slot_off(int par, int kind) { return (par * 4 
 // one 1-KiB LDS-DMA piece: global address = sbase (SGPR pair) + voff (VGPR, bytes), LDS address = ldsw + IMM + 16 * lane
 template <int IMM>
 __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_t ldsw) {
+    if constexpr (CM3P_G8P_ABL & 64) {
+        asm volatile("" ::"v"(voff), "s"(sbase), "s"(ldsw));
+        return;
+    }
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsw), "n"(IMM)
                  : "memory", "m0", "scc");
 }
@@ -144,7 +152,11 @@ struct Operand {
     }
 };
 
-template <bool A_KC, bool B_KC, int EPI>
+// REBAL: the B-lo fragments of k-tile t+1 are read in phase 4 of k-tile t (which has no fragment reads of its own) instead of in
+// phase 1 of t+1, the longest memory section (12 reads + DMA + the B-lo retire wait): r03 probe, -7 % on the long-K shapes with those
+// reads gone.  The two B register sets then swap roles every k-tile, so the k-loop is unrolled by two and every work item must
+// have an even number of k-tiles (the dispatcher sends other shapes to the plain instance).
+template <bool A_KC, bool B_KC, int EPI, bool REBAL>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                         int64_t ldc, int tiles_n, int ntiles, int total, int64_t kchunk,
@@ -222,7 +234,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 runs one barrier behind
 
-    // FIRST: the first k-tile of a work item starts its accumulators from the MFMA's zero operand instead of 128 v_mov per tile
+    // FIRST: the first k-tile of a work item starts its accumulators from the MFMA's zero operand instead of 128 v_mov per tile.
+    // The MFMAs are inline assembly with the accumulator tied to itself ("+v"): with several inlined copies of the k-tile body
+    // (first / steady, and the role-swapped pair of REBAL) the compiler otherwise gives every copy its own accumulator registers,
+    // moves them with D != C MFMAs and spills inside the clusters.  hipcc pads no hazards for an asm statement: operands come
+    // from ds_reads behind an explicit lgkmcnt(0), an accumulator is re-read as C eight MFMAs later (same vDst: forwarded by the
+    // hardware), and the epilogue reads the results behind explicit s_nops (matrix-result -> VALU / LDS read: up to 18 wait states).
     auto mma = [&](auto Fc, auto Ic, auto Jc, const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2]) {
         constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
         constexpr bool FIRST = decltype(Fc)::value && !(CM3P_G8P_ABL & 4);
@@ -233,8 +250,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 c = (FIRST && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[I * 4 + mt][J * 2 + nt];
-                    acc[I * 4 + mt][J * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[mt][kk], c, 0, 0, 0);
+                    f32x4& c = acc[I * 4 + mt][J * 2 + nt];
+                    if constexpr (FIRST) {
+                        if (kk == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(fb[nt][kk]), "v"(fa[mt][kk]));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(fb[nt][kk]), "v"(fa[mt][kk]));
+                    } else {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(fb[nt][kk]), "v"(fa[mt][kk]));
+                    }
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -243,16 +265,23 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
 
     // (one code path for both k-tile parities - the parity is a run-time 64 KiB offset: accumulators written in two branches
     //  that merge are duplicated by the compiler and spilled)
-    auto ktile = [&](int par, auto Fc) {
+    // fbl / fbh: the two B register sets.  !REBAL: B-lo / B-hi of this k-tile, both read here.  REBAL: fbl arrives holding this
+    // k-tile's B-lo (read during the previous k-tile) and fbh leaves holding the next k-tile's.
+    auto ktile = [&](int par, auto Fc, bf16x8 (&fbl)[2][2], bf16x8 (&fbh)[2][2]) {
         const int pofs = par << 16;                                         // this k-tile's four slots
         const uint32_t lds_p = ldsw + pofs, lds_q = ldsw + (pofs ^ 65536);  // LDS-DMA bases: this parity / the other one
-        bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
+        bf16x8 fa[4][2];
         // ---- phase 1: quadrant (A-lo, B-lo)
+        if constexpr (!REBAL) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fbl[nt][kk] = ob.frag(smem, pofs + slot_off(0, kBL), nt, kk);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int kk = 0; kk < 2; ++kk) {
+                    if constexpr (CM3P_G8P_ABL & 32) asm volatile("" : "=v"(fbl[nt][kk]));
+                    else fbl[nt][kk] = ob.frag(smem, pofs + slot_off(0, kBL), nt, kk);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -260,10 +289,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         __builtin_amdgcn_sched_barrier(0);
         glds_s<slot_off(0, kAH)>(vah, sah[0], lds_q);
         glds_s<slot_off(0, kAH) + 1024>(vah, sah[1], lds_q);
-        // the B-lo reads (issued first) are done, so B-lo may be restaged in the next phase: at most as many LDS operations
-        // outstanding as were issued behind them (8 ds_read_b128 or 16 ds_read_b64_tr_b16; the counter holds 15)
-        if constexpr (A_KC) G8P_WAIT_LGKM(8);
-        else G8P_WAIT_LGKM(15);
+        // !REBAL: the B-lo reads (issued first) are done, so B-lo may be restaged in the next phase: at most as many LDS operations
+        // outstanding as were issued behind them (8 ds_read_b128 or 16 ds_read_b64_tr_b16; the counter holds 15).  REBAL: B-lo was
+        // read three phases ago.
+        if constexpr (!REBAL) {
+            if constexpr (A_KC) G8P_WAIT_LGKM(8);
+            else G8P_WAIT_LGKM(15);
+        }
         __builtin_amdgcn_s_barrier();
         G8P_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -297,10 +329,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- phase 4: (A-hi, B-lo); the counted wait retires every half-tile of the next k-tile
+        if constexpr (REBAL) {
+            // B-lo of the NEXT k-tile (other parity; it landed before this k-tile began: retired by the previous k-tile's counted
+            // wait) into the set B-hi has just left; its slot is restaged two phases after the next k-tile starts
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fbh[nt][kk] = ob.frag(smem, (pofs ^ 65536) + slot_off(0, kBL), nt, kk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         ob.template stage<slot_off(0, kBH)>(1, lds_p);
         stream_advance();
         if constexpr (!(CM3P_G8P_ABL & 8)) G8P_WAIT_VM(6);
         __builtin_amdgcn_s_barrier();
+        if constexpr (REBAL) G8P_WAIT_LGKM(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(Fc, I1{}, I0{}, fa, fbl);
         __builtin_amdgcn_sched_barrier(0);
@@ -317,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         // the lane id is laundered so that the epilogue's address arithmetic is not hoisted out of the work-item loop and kept
         // alive (in registers the k-loop needs) across it
         int lane = lane_;
-        asm volatile("" : "+v"(lane));
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(lane));  // (and the asm MFMAs' last results are 24 wait states old before anything reads them)
         const int64_t mw = m0 + wr * 128, nw = n0 + wc * 64;
         if constexpr (CM3P_G8P_ABL & 2) {
 #pragma unroll
@@ -447,17 +489,33 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
     };
 
     int par = 0;
+    bf16x8 fbP[2][2], fbQ[2][2];
+    if constexpr (REBAL) {  // B-lo of the very first k-tile (the prologue's wait and barrier(s) are behind us)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fbP[nt][kk] = ob.frag(smem, slot_off(0, kBL), nt, kk);
+    }
     for (int v = blockIdx.x; v < total; v += gridDim.x) {
         int64_t m0, n0;
         int z;
         decode(v, m0, n0, z);
         const int64_t kbeg = (int64_t)z * kchunk;
         const int nk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
-        ktile(par, std::true_type{});
-        par ^= 1;
-        for (int kt = 1; kt < nk; ++kt) {
-            ktile(par, std::false_type{});
+        if constexpr (REBAL) {  // nk even (checked by the dispatcher): the register sets swap roles every k-tile
+            ktile(par, std::true_type{}, fbP, fbQ);
+            ktile(par ^ 1, std::false_type{}, fbQ, fbP);
+            for (int kt = 2; kt < nk; kt += 2) {
+                ktile(par, std::false_type{}, fbP, fbQ);
+                ktile(par ^ 1, std::false_type{}, fbQ, fbP);
+            }
+        } else {
+            ktile(par, std::true_type{}, fbP, fbQ);
             par ^= 1;
+            for (int kt = 1; kt < nk; ++kt) {
+                ktile(par, std::false_type{}, fbP, fbQ);
+                par ^= 1;
+            }
         }
         if (m0 + 256 <= M && n0 + 256 <= N) epilogue(std::true_type{}, m0, n0, z);
         else epilogue(std::false_type{}, m0, n0, z);
@@ -466,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
     G8P_WAIT_VM(0);                             // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool REBAL>
 int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
              int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
@@ -483,11 +541,11 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            if (hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
+            if (hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E, REBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
                 return CM3P_ERR_LAUNCH;                                                                                           \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm8p_kernel<A_KC, B_KC, E><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
+        gemm8p_kernel<A_KC, B_KC, E, REBAL><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G8P(CM3P_EPI_BF16) break;
@@ -521,10 +579,18 @@ int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, 
     if (lda * 2 * 8 >= (int64_t(1) << 31) || ldb * 2 * 8 >= (int64_t(1) << 31)) return CM3P_ERR_INVALID;  // 32-bit lane offsets
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(B);
-    if (a_kc && b_kc) return launch8p<true, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
-    if (a_kc) return launch8p<true, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
-    if (b_kc) return launch8p<false, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
-    return launch8p<false, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope);
+    // every work item's k-tile count even (the last k-split may be shorter): the instance whose B register sets swap roles
+    const int64_t last = K - (int64_t)(splits - 1) * kchunk;
+    static const bool no_rebal = [] { const char* e = getenv("CM3P_G8P_REBAL"); return e && e[0] == '0'; }();
+    const bool rebal = !no_rebal && (kchunk / 64) % 2 == 0 && (splits == 1 ? (K / 64) % 2 == 0 : (last > 0 && (last / 64) % 2 == 0));
+#define CM3P_G8P_GO(AK, BK)                                                                                                      \
+    return rebal ? launch8p<AK, BK, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope)        \
+                 : launch8p<AK, BK, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope)
+    if (a_kc && b_kc) CM3P_G8P_GO(true, true);
+    if (a_kc) CM3P_G8P_GO(true, false);
+    if (b_kc) CM3P_G8P_GO(false, true);
+    CM3P_G8P_GO(false, false);
+#undef CM3P_G8P_GO
 }
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)

@@ -57,30 +57,38 @@ def loops(body: str):
 # ------------------------------------------------------------------------------------------------ gemm8p.hip
 def check_gemm8p(isa: str):
     """The half-tile ring of gemm8p.hip: per k-tile exactly 8 LDS-DMA instructions (4 half-tiles x 2 pieces per wave), 8 raw
-    barriers, 64 MFMAs and ONE vector-memory wait, `s_waitcnt vmcnt(6)`, right in front of a barrier; the B-lo fragment reads are
-    retired by `lgkmcnt(8 | 15)` in front of the first barrier of phase 1; no scratch anywhere."""
+    barriers, 64 MFMAs and ONE vector-memory wait, `s_waitcnt vmcnt(6)`, right in front of a barrier; no scratch anywhere.
+    Plain instances (one k-tile per loop iteration): the B-lo fragment reads are retired by `lgkmcnt(8 | 15)` in front of the first
+    barrier of phase 1.  REBAL instances (two k-tiles per iteration, B register sets swapping roles): no such wait - B-lo is read
+    three phases before its slot is restaged.  The MFMAs are inline assembly with tied accumulators: D and C are the same
+    registers in every accumulating MFMA."""
     no_scratch(isa, "gemm8p.hip")
     bodies = kernel_bodies(isa, "gemm8p_kernel")
-    _need(len(bodies) >= 12, f"gemm8p.hip: {len(bodies)} kernel instances found")
+    _need(len(bodies) >= 24, f"gemm8p.hip: {len(bodies)} kernel instances found")
     for sym, body in bodies.items():
-        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_16x16x32_bf16") == 64]
-        _need(ring, f"{sym}: steady-state k-tile loop (64 MFMAs) not found")
+        rebal = sym.endswith("ELb1EEEvPKtS2_PvPKflllllliiill8RopeArgs")
+        n = 2 if rebal else 1
+        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_16x16x32_bf16") == 64 * n]
+        _need(ring, f"{sym}: steady-state k-loop ({64 * n} MFMAs) not found")
         seg = min(ring, key=len)
         dma = len(re.findall(r"\bglobal_load_lds_dwordx4\b", seg))
-        _need(dma == 8, f"{sym}: {dma} LDS-DMA instructions per k-tile, expected 8")
-        _need(seg.count("s_barrier") == 8, f"{sym}: {seg.count('s_barrier')} barriers per k-tile, expected 8")
+        _need(dma == 8 * n, f"{sym}: {dma} LDS-DMA instructions per loop iteration, expected {8 * n}")
+        _need(seg.count("s_barrier") == 8 * n, f"{sym}: {seg.count('s_barrier')} barriers per loop iteration, expected {8 * n}")
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", seg)
-        _need(waits == ["6"], f"{sym}: vector-memory waits in the k-tile loop are {waits}, expected one vmcnt(6)")
-        m = re.search(r"s_waitcnt vmcnt\(6\)", seg)
-        _need(re.match(r"\s*s_barrier", seg[m.end():]), f"{sym}: the counted wait is not directly in front of a barrier")
+        _need(waits == ["6"] * n, f"{sym}: vector-memory waits in the k-loop are {waits}, expected {n} x vmcnt(6)")
+        for m in re.finditer(r"s_waitcnt vmcnt\(6\)", seg):
+            _need(re.match(r"\s*s_barrier", seg[m.end():]), f"{sym}: a counted wait is not directly in front of a barrier")
         _need("scratch_" not in seg and not re.search(r"\b(buffer_|flat_|global_load_dword|global_store)", seg),
-              f"{sym}: stray memory instruction in the k-tile loop")
+              f"{sym}: stray memory instruction in the k-loop")
         lg = re.findall(r"s_waitcnt lgkmcnt\((8|15)\)\s*\n\s*s_barrier", seg)
-        _need(len(lg) == 1, f"{sym}: the B-lo retire wait (lgkmcnt(8|15) in front of phase 1's barrier) appears {len(lg)} times")
-        # whole kernel: prologue 14 pieces + two k-tile bodies (first / steady) of 8
+        _need(len(lg) == (0 if rebal else 1), f"{sym}: the B-lo retire wait (lgkmcnt(8|15) in front of phase 1's barrier) appears {len(lg)} times")
+        for m in re.finditer(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (\S+)", seg):
+            _need(m.group(1) == m.group(2), f"{sym}: an accumulating MFMA of the k-loop has D != C ({m.group(0)})")
+        # whole kernel: prologue 14 pieces + the inlined k-tile bodies (first + steady, x 2 for REBAL) of 8
         total = len(re.findall(r"\bglobal_load_lds_dwordx4\b", body))
-        _need(total == 30, f"{sym}: {total} LDS-DMA instructions in the kernel, expected 14 + 8 + 8")
+        _need(total == 14 + 16 * n, f"{sym}: {total} LDS-DMA instructions in the kernel, expected {14 + 16 * n}")
         _need(body.count("s_waitcnt vmcnt(0)") >= 1, f"{sym}: the final drain of the ring is missing")
+        _need(re.search(r"s_nop 15\s*\n\s*s_nop 7", body), f"{sym}: the epilogue's wait states behind the asm MFMAs are missing")
 
 
 # ------------------------------------------------------------------------------------------------ attention_bwd.hip
