@@ -100,12 +100,25 @@ def _big_gemm_kernel(M: int, N: int) -> str:
     return "gemm8p_kernel" if (M % 8 == 0 and N % 8 == 0 and not os.environ.get("CM3P_GEMM_IMPL", "").startswith("2")) else "gemm256_kernel"
 
 
+def _g8p_rebal(K: int, kchunk: int) -> bool:
+    """gemm8p.hip's instance choice (cm3p_gemm8p_dispatch): REBAL when every work item has an even number of 64-deep k-tiles."""
+    if os.environ.get("CM3P_G8P_REBAL", "1").startswith("0"):
+        return False
+    splits = max(1, -(-K // kchunk))
+    last = K - (splits - 1) * kchunk
+    return (kchunk // 64) % 2 == 0 and ((K // 64) % 2 == 0 if splits == 1 else (last > 0 and (last // 64) % 2 == 0))
+
+
 def _gemm_tag(M: int, N: int, K: int, a_kc, b_kc, epilogue, split_k: int) -> str:
     """Profiler tag = the kernel the library will pick (same rule as cm3p_gemm_bf16 in csrc/gemm.hip), spelled like rocprof."""
     kchunk = K if split_k <= 1 else -(-(-(-K // split_k)) // 64) * 64
     big = K % 64 == 0 and kchunk % 64 == 0 and (-(-M // 256)) * (-(-N // 256)) * max(1, -(-K // kchunk)) >= 200
     b2s = lambda v: "true" if v else "false"
-    return f"{_big_gemm_kernel(M, N) if big else 'gemm_bf16_kernel'}<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}>"
+    if not big:
+        return f"gemm_bf16_kernel<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}>"
+    name = _big_gemm_kernel(M, N)
+    tail = f", {b2s(_g8p_rebal(K, kchunk))}" if name == "gemm8p_kernel" else ""
+    return f"{name}<{b2s(a_kc)}, {b2s(b_kc)}, {epilogue}{tail}>"
 
 
 def gemm(a: Tensor, b: Tensor, M: int, N: int, K: int, a_kc: bool, b_kc: bool, epilogue: int,
@@ -137,7 +150,7 @@ def qkv_linear_rope(x: Tensor, w: Tensor, cos: Tensor, sin: Tensor, S: int, per_
     N = w.shape[0]
     out = _empty((T, N), torch.bfloat16, x)
     call("cm3p_qkv_gemm_rope", ptr(x), ptr(w), ptr(out), T, N, Kd, ptr(cos, torch.float32), ptr(sin, torch.float32), S, int(per_batch), 2 * N // 3, float(q_scale), stream(),
-         tag=(_big_gemm_kernel(T, N) if (Kd % 64 == 0 and (-(-T // 256)) * (-(-N // 256)) >= 200) else "gemm_bf16_kernel") + "<true, true, 3>",
+         tag=_gemm_tag(T, N, Kd, True, True, 3, 1) if (2 * N // 3) % 256 == 0 else "gemm_bf16_kernel<true, true, 3>",
          work=2.0 * T * N * Kd)
     return out
 
