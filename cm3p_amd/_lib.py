@@ -42,7 +42,6 @@ SIGNATURES = {
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
     "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "cm3p_attn_probs": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "cm3p_attn_bwd_band": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _L, _I, _I, _P],
     "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _I, _P],
     "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
     "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],

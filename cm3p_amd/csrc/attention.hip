@@ -622,281 +622,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Sliding-window backward as ONE owner-workgroup kernel (r03; window <= 64): a workgroup owns 128 rows of one (batch, head) as
-// queries AND as keys.  It brings the four 64-row tiles that cover rows [R0 - 64, R0 + 192) - the owned rows and one halo tile on
-// each side - into LDS once (Q, dO, K, V images, the rows' lse / delta, the keys' validity: 33 KiB per tile), then each wave runs
-// the dq sweep of attn_bwd_dq_kernel for its 32 queries and the dk / dv sweep of attn_bwd_dkv_kernel for its 32 keys over those
-// tiles.  Same products in the same order as the two-kernel path (bit-identical results; the halo's scores are recomputed by the
-// neighbouring workgroups instead of being exchanged), but q / k / v / dO are read 2 x (owned + halo) instead of 3 x by two
-// launches, there is one prologue and one launch per layer, and the four tiles arrive as one DMA burst.
-// delta = rowsum(dO o O) comes from attn_delta_kernel (the halo rows' deltas belong to other workgroups).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kBandTile = 4 * 8192 + 1024;  // Q, dO, K, V images; lse[64], delta[64], key validity dwords[64], 256 spare
-constexpr int kBandLds = 4 * kBandTile + 4 * 4608;  // + one transposition buffer per wave (store_rows32)
-
-// grid (ceil(S / 64), nh, B), 256 threads: four threads per row
-__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o_rows, const uint16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int Smax, int nh, VarLen vl) {
-    const int t = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const SeqView sv(vl, b, head, Smax, nh);
-    const int row = t * 64 + (tid >> 2), part = tid & 3;
-    if (row >= sv.S) return;  // (whole groups of four lanes leave together: the shuffles below stay inside a group)
-    const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* po = o_rows + (sv.row0 + row) * ldo + head * 64 + part * 16;
-    const uint16_t* pg = d_o + (sv.row0 + row) * ldo + head * 64 + part * 16;
-    float acc = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(po + 8 * h), g = *reinterpret_cast<const bf16x8*>(pg + 8 * h);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)g[j];
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) delta[sv.stat0 + row] = acc;
-}
-
-template <bool PRE, bool MASK>
-__global__ __launch_bounds__(256, 1) void attn_bwd_band_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
-                                                               int nh, int window, float scale, const float* __restrict__ rope_cos,
-                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int blk128, head, b;
-    decode_block((Smax + 127) / 128, nh, blk128, head, b);
-    const int R0 = blk128 * 128;
-    const SeqView sv(vl, b, head, Smax, nh);
-    const int S = sv.S;
-    if (R0 >= S) return;
-    const int r0 = R0 + wid * 32;  // the wave's 32 rows: its queries and its keys
-    const int64_t ld = (int64_t)3 * nh * 64;
-    const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
-    const uint16_t* kbase = qbase + nh * 64;
-    const uint16_t* vbase = qbase + 2 * nh * 64;
-    const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* dobase = d_o + sv.row0 * ldo + head * 64;
-    const float* lse_bh = lse + sv.stat0;
-    const float* dlt_bh = delta + sv.stat0;
-    const int T0 = R0 / 64 - 1;  // global number of tile slot 0 (may be -1: no rows before the sequence)
-    const int NT = (S + 63) / 64;
-
-    // ---- one DMA burst: every tile that exists, then a single wait.  Per tile and wave: Q, dO, K, V pieces (8 operations); wave 0
-    // adds the lse / delta rows and, with a key mask, the validity bytes (zero-extended to dwords).
-    const TileDma dma(wid, lane);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t m0_w = __builtin_amdgcn_readfirstlane(lds0 + 2048u * wid);
-    const uint8_t* km = MASK ? kmask + sv.row0 : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int t = T0 + j;
-        if (t < 0 || t >= NT) continue;
-        const uint32_t slot = (uint32_t)j * kBandTile;
-        dma.rows(m0_w + slot, qbase, (int)ld * 2, t * 64, S);
-        dma.rows(m0_w + slot + 8192u, dobase, (int)ldo * 2, t * 64, S);
-        dma.rows(m0_w + slot + 16384u, kbase, (int)ld * 2, t * 64, S);
-        dma.rows(m0_w + slot + 24576u, vbase, (int)ld * 2, t * 64, S);
-        if (wid == 0) {
-            const uint32_t so = (uint32_t)(min(t * 64 + lane, S - 1) * 4);
-            dma_dword64(lds0 + slot + 32768u, lse_bh, so);
-            dma_dword64(lds0 + slot + 32768u + 256u, dlt_bh, so);
-            if constexpr (MASK) dma_ubyte64(lds0 + slot + 32768u + 512u, km, (uint32_t)min(t * 64 + lane, S - 1));
-        }
-    }
-    // the rotary rows of both epilogues (the wave's rows are its queries and its keys) are requested behind the burst
-    const int row = r0 + (lane & 31);
-    const int row_c = row < S ? row : S - 1;
-    f32x4 rcs[4], rsn[4];
-    if (rope_cos) {
-        const int64_t prow = sv.pos0(b, pos_batch_stride) + row_c;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            rcs[g] = *reinterpret_cast<const f32x4*>(rope_cos + prow * 32 + 8 * g + 4 * hh);
-            rsn[g] = *reinterpret_cast<const f32x4*>(rope_sin + prow * 32 + 8 * g + 4 * hh);
-        }
-    }
-    dma_wait(0);
-    if (wid == 0) {  // rows past the sequence were read from row S - 1: lse = +inf (p = 0), delta = 0
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = T0 + j;
-            if (t < 0 || t >= NT) continue;
-            if (t * 64 + lane >= S) {
-                reinterpret_cast<float*>(smem + j * kBandTile + 32768)[lane] = __builtin_huge_valf();
-                reinterpret_cast<float*>(smem + j * kBandTile + 32768 + 256)[lane] = 0.f;
-            }
-        }
-    }
-    lds_only_barrier();
-
-    const bool wave_live = r0 < S;
-    const int wlo = max(0, r0 - window), whi = min(S - 1, r0 + 31 + window);  // rows this wave's 32 rows interact with
-    const float c = scale * kLog2e;
-    const char* own = smem + (1 + (wid >> 1)) * kBandTile;  // the tile that holds the wave's rows ...
-    const int orow = 32 * (wid & 1);                        // ... and where in it
-    char* zbuf = smem + 4 * kBandTile + 4608 * wid;
-
-    // ======== dq sweep (attn_bwd_dq_kernel's body): queries = the wave's rows, keys = the tiles ========
-    if (wave_live) {
-        bf16x8 qf[4], dof[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            qf[s] = frag_R(own, orow, s, lane);
-            dof[s] = frag_R(own + 8192, orow, s, lane);
-        }
-        const float lse_raw = reinterpret_cast<const float*>(own + 32768)[orow + (lane & 31)];
-        const float dlt = reinterpret_cast<const float*>(own + 32768 + 256)[orow + (lane & 31)];
-        const float lse2 = PRE ? lse_raw * kLog2e : lse_raw / scale;
-        const int lo = row - window, hi = min(row + window, S - 1);  // (keys past S: cut here)
-        f32x16 dq[2], lse_init, dlt_init;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dq[0][i] = dq[1][i] = 0.f;
-            lse_init[i] = -lse2;
-            dlt_init[i] = -dlt;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = T0 + j, key0 = t * 64;
-            if (t < 0 || t >= NT || key0 > whi || key0 + 63 < wlo) continue;
-            const char* st = smem + j * kBandTile + 16384;  // K image, V image at + 8192
-            const uint32_t* mb = reinterpret_cast<const uint32_t*>(smem + j * kBandTile + 32768 + 512);
-            int all_valid = key0 + 63 < S;
-            if constexpr (MASK) all_valid = all_valid && __all(mb[lane] != 0u);
-            const bool unmasked = tile_unmasked(all_valid, key0, r0, window);
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                if (key0 + 32 * blk > whi || key0 + 32 * blk + 31 < wlo) continue;
-                f32x16 sacc = mfma32(frag_R(st, 32 * blk, 0, lane), qf[0], lse_init);
-                f32x16 dp = mfma32(frag_R(st + 8192, 32 * blk, 0, lane), dof[0], dlt_init);
-#pragma unroll
-                for (int s = 1; s < 4; ++s) {
-                    sacc = mfma32(frag_R(st, 32 * blk, s, lane), qf[s], sacc);
-                    dp = mfma32(frag_R(st + 8192, 32 * blk, s, lane), dof[s], dp);
-                }
-                if (!unmasked) mask_scores_keyrows_d<MASK>(sacc, mb, blk, key0, lo, hi, hh);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
-                    sacc[i] = p * dp[i];  // dS^T / scale (the scale is applied once, to dQ)
-                }
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const bf16x8 dsf = acc_to_frag(sacc, sp);
-                    dq[0] = mfma32(frag_T(st, 32 * blk + 16 * sp, 0, lane), dsf, dq[0]);
-                    dq[1] = mfma32(frag_T(st, 32 * blk + 16 * sp, 1, lane), dsf, dq[1]);
-                }
-            }
-        }
-        if (rope_cos) {  // backward of apply_rotary_pos_emb: dims d / d + 32 are the lane's two accumulator blocks
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = dq[0][4 * g + r], b0 = dq[1][4 * g + r];
-                    dq[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
-                    dq[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
-                }
-        }
-        store_rows32(zbuf, dq[0], dq[1], scale, dqkv + (sv.row0 + r0) * ld + head * 64, ld, S - r0, lane);
-    }
-
-    // ======== dk / dv sweep (attn_bwd_dkv_kernel's body): keys = the wave's rows, queries = the tiles ========
-    if (wave_live) {
-        bf16x8 kf[4], vf[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kf[s] = frag_R(own + 16384, orow, s, lane);
-            vf[s] = frag_R(own + 24576, orow, s, lane);
-        }
-        bool key_ok = row < S;
-        if constexpr (MASK) key_ok = key_ok && reinterpret_cast<const uint32_t*>(own + 32768 + 512)[orow + (lane & 31)] != 0u;
-        const bool keys_all_ok = __all(key_ok);
-        const int lo = row - window, hi = row + window;
-        const float lse_mul = PRE ? -kLog2e : -1.0f / scale;
-        f32x16 dk[2], dv[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = T0 + j, qt0 = t * 64;
-            if (t < 0 || t >= NT || qt0 > whi || qt0 + 63 < wlo) continue;
-            const char* st = smem + j * kBandTile;  // Q image, dO image at + 8192
-            const float* nlse = reinterpret_cast<const float*>(st + 32768);
-            const float* ndlt = nlse + 64;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                if (qt0 + 32 * qb > whi || qt0 + 32 * qb + 31 < wlo) continue;
-                f32x16 sacc, dp;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 32 * qb + 8 * g + 4 * hh);
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(ndlt + 32 * qb + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sacc[4 * g + r] = a[r] * lse_mul;
-                        dp[4 * g + r] = -d[r];
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    sacc = mfma32(frag_R(st, 32 * qb, s, lane), kf[s], sacc);      // log2 p: rows q, col key
-                    dp = mfma32(frag_R(st + 8192, 32 * qb, s, lane), vf[s], dp);   // dP - delta
-                }
-                const int qb0 = qt0 + 32 * qb;
-                const bool plain = keys_all_ok && (qb0 >= r0 + 31 - window && qb0 + 31 <= r0 + window);
-                if (plain) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
-                        sacc[i] = p;
-                        dp[i] = p * dp[i];  // dS / scale (applied once, to dK)
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = 4 * g + r;
-                            const int q = qb0 + 8 * g + 4 * hh + r;
-                            const bool ok = key_ok & (q >= lo) & (q <= hi);
-                            const float p = ok ? __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c) : 0.f;
-                            sacc[i] = p;
-                            dp[i] = p * dp[i];
-                        }
-                }
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const bf16x8 pf = acc_to_frag(sacc, sp);
-                    const bf16x8 dsf = acc_to_frag(dp, sp);
-                    const int rr = 32 * qb + 16 * sp;
-                    dv[0] = mfma32(frag_T(st + 8192, rr, 0, lane), pf, dv[0]);
-                    dv[1] = mfma32(frag_T(st + 8192, rr, 1, lane), pf, dv[1]);
-                    dk[0] = mfma32(frag_T(st, rr, 0, lane), dsf, dk[0]);
-                    dk[1] = mfma32(frag_T(st, rr, 1, lane), dsf, dk[1]);
-                }
-            }
-        }
-        if (rope_cos) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = dk[0][4 * g + r], b0 = dk[1][4 * g + r];
-                    dk[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
-                    dk[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
-                }
-        }
-        // PRE: the products were taken with q * scale * log2(e), so dK = ln(2) * accumulator
-        uint16_t* dk0 = dqkv + (sv.row0 + r0) * ld + nh * 64 + head * 64;
-        store_rows32(zbuf, dk[0], dk[1], PRE ? 0.69314718055994531f : scale, dk0, ld, S - r0, lane);
-        store_rows32(zbuf, dv[0], dv[1], 1.0f, dk0 + nh * 64, ld, S - r0, lane);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // output_attentions: the probabilities themselves, [B, nh, S, S] fp32 - what the reference returns when a caller asks for
 // attention weights (TF then runs eager_attention_forward, TF:models/modernbert/modeling_modernbert.py:133-170: softmax of
 // scale * q k^T + additive mask in fp32).  An inspection path, not a hot one: p[q, k] = exp(scale * q.k - lse[q]) from the lse the
@@ -1076,45 +801,6 @@ int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, 
     CM3P_REQUIRE(qkv && lse && probs && B > 0 && S > 0 && nh > 0 && scale > 0.f && cm3p_aligned16(qkv));
     attn_probs_kernel<<<dim3((S + 63) / 64, nh, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const uint16_t*>(qkv), lse, key_mask, probs, S, nh, window, q_prescaled ? 1.0f : scale * kLog2e);
-    CM3P_LAUNCH_CHECK();
-    return CM3P_OK;
-}
-
-/* Sliding-window backward as one owner-workgroup kernel (attn_bwd_band_kernel above); 0 <= window <= 64.
- * stages: CM3P_ATTN_BWD_BAND_DELTA (delta = rowsum(dO o O) -> `delta`) | CM3P_ATTN_BWD_BAND_MAIN (dq, dk, dv; reads `delta`). */
-int cm3p_attn_bwd_band(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                       const uint8_t* key_mask, const int* cu_seqlens, int B, int S, int64_t total, int nh, int window, float scale,
-                       const float* cos_tab, const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream) {
-    CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
-    CM3P_REQUIRE(stages >= 1 && stages <= 3 && window >= 0 && window <= 64);
-    CM3P_REQUIRE(qkv && out && dout && lse && delta && dqkv && B > 0 && S > 0 && nh > 0 && scale > 0.f);
-    CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv));
-    if (cu_seqlens) CM3P_REQUIRE(total > 0 && key_mask == nullptr && pos_batch_stride == 0);
-    else CM3P_REQUIRE(pos_batch_stride == 0 || pos_batch_stride == S);
-    CM3P_REQUIRE((int64_t)S * 3 * nh * 128 < (int64_t(1) << 31));  // TileDma::rows: 32-bit row * pitch source offsets
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const VarLen vl{cu_seqlens, cu_seqlens ? total : 0};
-    if (stages & CM3P_ATTN_BWD_BAND_DELTA) {
-        attn_delta_kernel<<<dim3((S + 63) / 64, nh, B), 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, S, nh, vl);
-        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
-    }
-    if (stages & CM3P_ATTN_BWD_BAND_MAIN) {
-        static const bool attr = [] {
-            const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, false>),
-                                reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, false>)};
-            for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kBandLds);
-            return true;
-        }();
-        (void)attr;
-        const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-        const bool pre = q_prescaled != 0;
-#define CM3P_BAND_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        if (pre && key_mask) attn_bwd_band_kernel<true, true><<<grid, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else if (pre) attn_bwd_band_kernel<true, false><<<grid, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else if (key_mask) attn_bwd_band_kernel<false, true><<<grid, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else attn_bwd_band_kernel<false, false><<<grid, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-#undef CM3P_BAND_ARGS
-    }
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

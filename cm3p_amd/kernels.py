@@ -15,7 +15,7 @@ from ._lib import BF16, EPI_BF16, EPI_F32, EPI_F32_RESID, F32, call, dt, ptr, qu
 Tensor = torch.Tensor
 
 # C-ABI calls whose `work` is algorithmic BYTES (HBM-bound row-wise kernels); every other `work` is matmul FLOPs
-_lib.HBM_BOUND_TAGS.update({"attn_delta_kernel [local]", "attn_delta_kernel [local, varlen]", "cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd", "attn_bwd_prep_kernel [global]",
+_lib.HBM_BOUND_TAGS.update({"cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd", "attn_bwd_prep_kernel [global]",
                             "attn_bwd_dq_reduce_kernel [global]", "attn_bwd_prep_kernel [global, varlen]", "attn_bwd_dq_reduce_kernel [global, varlen]"})
 
 
@@ -276,34 +276,6 @@ def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, r
     return dqkv
 
 
-ATTN_BWD_BAND_DELTA, ATTN_BWD_BAND_MAIN = 1, 2  # stages of cm3p_attn_bwd_band
-
-
-def attn_bwd_band_enabled(window: int) -> bool:
-    """Sliding-window layers (0 <= window <= 64) run the owner-workgroup kernel (csrc/attention.hip attn_bwd_band_kernel) unless
-    CM3P_ATTN_BWD_BAND=0 (then the query-parallel + key-parallel pair; bit-identical results)."""
-    return 0 <= window <= 64 and os.environ.get("CM3P_ATTN_BWD_BAND", "1") != "0"
-
-
-def _attn_bwd_band(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, window, scale, rope, per_batch, prescaled) -> Tensor:
-    dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
-    cos, sin = rope if rope is not None else (None, None)
-    varlen = cu is not None
-    rows = total if varlen else B * S
-    keys = min(S, 2 * window + 1)
-    b2s = lambda v: "true" if v else "false"
-    for stage, name, work in (
-        (ATTN_BWD_BAND_DELTA, "attn_delta_kernel", 2.0 * rows * nh * 64 * 2 + 4.0 * rows * nh),
-        (ATTN_BWD_BAND_MAIN, f"attn_bwd_band_kernel<{b2s(prescaled)}, {b2s(key_mask is not None)}>", 8.0 * B * nh * S * keys * 64),
-    ):
-        call("cm3p_attn_bwd_band", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8),
-             ptr(cu, torch.int32), B, S, total if varlen else 0, nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32),
-             S if (per_batch and not varlen) else 0, stage, int(prescaled), stream(),
-             tag=f"{name} [local{', varlen' if varlen else ''}]", work=None if (varlen and stage == ATTN_BWD_BAND_MAIN) else work)
-    return dqkv
-
-
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int,
              window: int, scale: float, rope: Optional[tuple] = None, per_batch: bool = False, prescaled: bool = False) -> Tensor:
     """rope = (cos, sin): also applies the inverse rotary rotation to dq / dk (backward of the fused Wqkv+RoPE GEMM).
@@ -312,8 +284,6 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     dkv kernel's); the scores each kernel recomputes are not credited."""
     if window < 0 and attn_bwd_fused_enabled():
         return _attn_bwd_fused(qkv, out, dout, lse, key_mask, None, B, S, 0, nh, scale, rope, per_batch, prescaled)
-    if attn_bwd_band_enabled(window):
-        return _attn_bwd_band(qkv, out, dout, lse, key_mask, None, B, S, 0, nh, window, scale, rope, per_batch, prescaled)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     keys = S if window < 0 else min(S, 2 * window + 1)
@@ -342,8 +312,6 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     """rope = (cos, sin) per packed token [total, 32]: also applies the inverse rotation to dq / dk."""
     if window < 0 and attn_bwd_fused_enabled():
         return _attn_bwd_fused(qkv, out, dout, lse, None, cu, B, max_s, qkv.shape[0], nh, scale, rope, False, prescaled)
-    if attn_bwd_band_enabled(window):
-        return _attn_bwd_band(qkv, out, dout, lse, None, cu, B, max_s, qkv.shape[0], nh, window, scale, rope, False, prescaled)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)

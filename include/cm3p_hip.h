@@ -301,19 +301,6 @@ int cm3p_pointwise_loss(const float* x, const float* y, float* out, float* dx, i
 /* idx[b] = first v with classes[b, v] == 0, else 0: `(classes == 0).int().argmax(dim=1)` (ref:cm3p/modeling_cm3p.py:40). */
 int cm3p_first_zero_index(const int64_t* classes, int B, int V, int64_t* idx, void* stream);
 
-/* The sliding-window backward (0 <= window <= 64: ModernBERT's local_attention 128) as ONE owner-workgroup kernel: a workgroup owns
- * 128 rows of one (batch, head) as queries and as keys, loads the four 64-row tiles that cover them and one halo tile on each side
- * into LDS once and runs both sweeps of cm3p_attn_bwd (window >= 0) over them - the same products in the same order, hence
- * bit-identical dq / dk / dv - with q / k / v / dO read twice instead of three times and one launch instead of two.
- * Padded batches: cu_seqlens = NULL, total = 0; unpadded: cu_seqlens [B + 1], S = max_seqlen, total rows, key_mask NULL,
- * pos_batch_stride 0, lse / delta [nh, total] (as cm3p_attn_bwd_varlen).  delta: caller-owned scratch shaped like lse.
- * stages: CM3P_ATTN_BWD_BAND_DELTA (delta = rowsum(dO o O)) | CM3P_ATTN_BWD_BAND_MAIN; both, in this order, on one stream. */
-#define CM3P_ATTN_BWD_BAND_DELTA 1
-#define CM3P_ATTN_BWD_BAND_MAIN 2
-int cm3p_attn_bwd_band(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                       const uint8_t* key_mask, const int* cu_seqlens, int B, int S, int64_t total, int nh, int window, float scale,
-                       const float* cos_tab, const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream);
-
 /* ---- Unpadded ("varlen") execution (ref:cm3p/modeling_cm3p.py:65-134 _unpad_cm3p_input / _pad_cm3p_output, :911-931;
  * the flash_attn_varlen path of TF:models/modernbert/modeling_modernbert.py).  Valid tokens are packed back to back:
  * sequence b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 (int32, B+1 entries, device) of qkv [total, 3, nh, 64],

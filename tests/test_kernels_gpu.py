@@ -667,32 +667,3 @@ def test_dgrad_through_transposed_weight_equals_strided_dgrad(K, T, N, K_):
     assert torch.equal(a, b)
     ref = dy[:256].float() @ w.float()
     assert (b[:256].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
-
-
-@pytest.mark.parametrize("prescaled", [False, True])
-@pytest.mark.parametrize("S,lens,window", [(1100, [1100, 777, 300], 64), (512, None, 64), (129, [129, 65, 1], 64), (700, [700, 333, 64], 17), (64, None, 64)])
-def test_sliding_window_backward_owner_kernel_is_bit_identical_to_the_pair(K, monkeypatch, S, lens, window, prescaled):
-    """attn_bwd_band_kernel (one workgroup owns 128 rows as queries and keys, halo tiles recomputed) runs the same products in the
-    same order as the query-parallel + key-parallel pair: dq, dk, dv equal bit for bit - ragged key padding, sequences that end inside
-    a tile / inside the first halo, both q modes, the RoPE epilogue - and the padded keys' rows are exact zeros."""
-    B, nh = (3 if lens else 2), 3
-    g = torch.Generator().manual_seed(S + window)
-    qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g) * 0.8).to(DEV)
-    do = _bf(torch.randn(B * S, nh * 64, generator=g)).to(DEV)
-    km = None
-    if lens:
-        km = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).to(torch.uint8).to(DEV)
-    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=DEV, dtype=torch.float32) / 64))
-    cos, sin = K.rope_table(torch.arange(S, device=DEV), inv_freq)
-    out, lse = K.attn_fwd(qkv, km, B, S, nh, window, 0.125, prescaled=prescaled)
-    monkeypatch.setenv("CM3P_ATTN_BWD_BAND", "1")
-    a = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, window, 0.125, (cos, sin), False, prescaled=prescaled)
-    a2 = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, window, 0.125, (cos, sin), False, prescaled=prescaled)
-    monkeypatch.setenv("CM3P_ATTN_BWD_BAND", "0")
-    b = K.attn_bwd(qkv, out, do, lse, km, B, S, nh, window, 0.125, (cos, sin), False, prescaled=prescaled)
-    torch.cuda.synchronize()
-    assert torch.isfinite(a.float()).all()
-    assert torch.equal(a, a2) and torch.equal(a, b)
-    if km is not None:
-        dead = (km == 0).view(B, S)
-        assert a[:, :, 1:][dead].abs().max().item() == 0.0
