@@ -353,7 +353,10 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
     void* out = C;
     int64_t split_stride = 0;
     if (split_k > 1) {
-        kchunk = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
+        // k-split length: a multiple of 128 where K allows it, so that every work item has an even number of 64-deep k-tiles
+        // (gemm8p.hip's REBAL instances need that) - the last split absorbs the remainder, itself a multiple of 128 then
+        const int64_t q = (K % 128 == 0) ? 128 : BK;
+        kchunk = ((K + split_k - 1) / split_k + q - 1) / q * q;
         split_k = (int)((K + kchunk - 1) / kchunk);
     }
     if (split_k > 1) {

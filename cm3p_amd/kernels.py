@@ -111,7 +111,8 @@ def _g8p_rebal(K: int, kchunk: int) -> bool:
 
 def _gemm_tag(M: int, N: int, K: int, a_kc, b_kc, epilogue, split_k: int) -> str:
     """Profiler tag = the kernel the library will pick (same rule as cm3p_gemm_bf16 in csrc/gemm.hip), spelled like rocprof."""
-    kchunk = K if split_k <= 1 else -(-(-(-K // split_k)) // 64) * 64
+    q = 128 if K % 128 == 0 else 64  # (csrc/gemm.hip: k-split lengths are multiples of 128 where K allows it)
+    kchunk = K if split_k <= 1 else -(-(-(-K // split_k)) // q) * q
     big = K % 64 == 0 and kchunk % 64 == 0 and (-(-M // 256)) * (-(-N // 256)) * max(1, -(-K // kchunk)) >= 200
     b2s = lambda v: "true" if v else "false"
     if not big:
