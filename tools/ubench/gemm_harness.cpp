@@ -85,6 +85,28 @@ static void impl(const char* s) { setenv("CM3P_GEMM_IMPL", s, 1); }
 
 int main(int argc, char** argv) {
     bool do_check = argc < 2, do_time = argc < 2;
+    if (argc >= 9 && !strcmp(argv[1], "one")) {  // one M N K epi a_kc b_kc splits [impl]: 20 launches of one shape (for rocprofv3 --pmc)
+        const char* libpath1 = getenv("CM3P_HIP_LIB") ? getenv("CM3P_HIP_LIB") : "cm3p_amd/csrc/libcm3p_hip.so";
+        void* lib1 = dlopen(libpath1, RTLD_NOW);
+        if (!lib1) return 2;
+        cm3p_gemm_bf16 = (gemm_fn)dlsym(lib1, "cm3p_gemm_bf16");
+        const int64_t M = atoll(argv[2]), N = atoll(argv[3]), K = atoll(argv[4]);
+        const int epi = atoi(argv[5]), a_kc = atoi(argv[6]), b_kc = atoi(argv[7]), splits = atoi(argv[8]);
+        impl(argc > 9 ? argv[9] : "8p");
+        Guarded A, B, R, C;
+        A.alloc(M * K * 2); B.alloc(N * K * 2); R.alloc(M * N * 4); C.alloc(M * N * 4);
+        float* ws1;
+        CK(hipMalloc(&ws1, (size_t)std::max(1, splits) * M * N * 4));
+        fill_bf16<<<1024, 256>>>((uint16_t*)A.p(), M * K, 1u, 1.f);
+        fill_bf16<<<1024, 256>>>((uint16_t*)B.p(), N * K, 2u, 1.f);
+        fill_f32<<<1024, 256>>>((float*)R.p(), M * N, 3u);
+        for (int i = 0; i < 20; ++i)
+            cm3p_gemm_bf16(A.p(), B.p(), C.p(), epi == CM3P_EPI_F32_RESID ? (const float*)R.p() : nullptr, M, N, K, a_kc ? K : M, b_kc ? K : N, N, a_kc, b_kc, epi,
+                           splits, ws1, nullptr);
+        CK(hipDeviceSynchronize());
+        printf("ran 20 launches of [%ld x %ld x %ld]\n", (long)M, (long)N, (long)K);
+        return 0;
+    }
     for (int i = 1; i < argc; ++i) {
         do_check |= !strcmp(argv[i], "check");
         do_time |= !strcmp(argv[i], "time");
