@@ -28,6 +28,9 @@
 //             - exponentials carry the hardware clamp (v_exp_f32 ... clamp): p <= 1 also for keys under the padding mask, whose
 //               scores the row maximum does not bound, so dS stays finite and meets the zero K row as an exact zero.
 //   reduce  dq = scale * inverse_rope(sum of the key blocks' bf16 slabs, fp32, fixed order) -> the q third of dqkv.
+//           (r03: the same sum done inside the fused kernel by the last workgroup of a (batch, head) to finish - ticket counter,
+//           agent-scope fences, bit-identical - was SLOWER, 5.40 vs 4.00 + 0.68 ms at B = 32, S = 4096: a reducing CU has four
+//           waves and gets 10 GB/s out of a loaded memory system, and its matrix cores idle meanwhile.  DESIGN.md.)
 //
 // Workspace (caller-owned, cm3p_attn_bwd_fused_workspace_bytes): the tile statistics and the slabs
 // [B * nh][key blocks][64 * tiles + 64 dump rows][64] bf16 (C2: 3.3 GB, C4: 6.5 GB - sized for 288 GB of HBM).
@@ -115,12 +118,12 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
 }
 
 // ---- reduce ---------------------------------------------------------------------------------------------------------------------
-// grid (tiles, nh, B), 256 threads: four threads per query row, each owns head dims [8j, 8j+8) and [32+8j, 32+8j+8)
-__global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int Smax,
-                                                                 int nh, float scale, const float* __restrict__ rope_cos,
-                                                                 const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
-    const int t = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const SeqView sv(vl, b, head, Smax, nh);
+// One 64-row tile of one (batch, head) by 256 threads: four threads per query row, each owns head dims [8j, 8j+8) and [32+8j, 32+8j+8).
+// The slabs are summed in key-block order, 16 at a time with all 32 loads of a thread in flight.
+__device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int t, int head, int b,
+                                               int tid, const SeqView& sv, int Smax, int nh, float scale,
+                                               const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                               int64_t pos_batch_stride) {
     const int S = sv.S;
     const int row = t * 64 + (tid >> 2), j = tid & 3;
     if (row >= S) return;
@@ -130,14 +133,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t*
     float lo[8], hi[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) lo[i] = hi[i] = 0.f;
-#pragma unroll 4
-    for (int kb = 0; kb < nkb_b; ++kb) {
-        const uint4 a = *reinterpret_cast<const uint4*>(p + kb * slab);
-        const uint4 c = *reinterpret_cast<const uint4*>(p + kb * slab + 32);
-        lo[0] += bf16lo(a.x), lo[1] += bf16hi(a.x), lo[2] += bf16lo(a.y), lo[3] += bf16hi(a.y);
-        lo[4] += bf16lo(a.z), lo[5] += bf16hi(a.z), lo[6] += bf16lo(a.w), lo[7] += bf16hi(a.w);
-        hi[0] += bf16lo(c.x), hi[1] += bf16hi(c.x), hi[2] += bf16lo(c.y), hi[3] += bf16hi(c.y);
-        hi[4] += bf16lo(c.z), hi[5] += bf16hi(c.z), hi[6] += bf16lo(c.w), hi[7] += bf16hi(c.w);
+    for (int kb0 = 0; kb0 < nkb_b; kb0 += 16) {
+        uint4 a[16], c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int kb = min(kb0 + u, nkb_b - 1);  // (past the last block: a repeated load, not summed)
+            a[u] = *reinterpret_cast<const uint4*>(p + kb * slab);
+            c[u] = *reinterpret_cast<const uint4*>(p + kb * slab + 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (kb0 + u < nkb_b) {
+                lo[0] += bf16lo(a[u].x), lo[1] += bf16hi(a[u].x), lo[2] += bf16lo(a[u].y), lo[3] += bf16hi(a[u].y);
+                lo[4] += bf16lo(a[u].z), lo[5] += bf16hi(a[u].z), lo[6] += bf16lo(a[u].w), lo[7] += bf16hi(a[u].w);
+                hi[0] += bf16lo(c[u].x), hi[1] += bf16hi(c[u].x), hi[2] += bf16lo(c[u].y), hi[3] += bf16hi(c[u].y);
+                hi[4] += bf16lo(c[u].z), hi[5] += bf16hi(c[u].z), hi[6] += bf16lo(c[u].w), hi[7] += bf16hi(c[u].w);
+            }
+        }
     }
     if (rope_cos) {
         const int64_t prow = sv.pos0(b, pos_batch_stride) + row;
@@ -158,6 +170,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t*
                                             pack_bf16x2(lo[4] * scale, lo[5] * scale), pack_bf16x2(lo[6] * scale, lo[7] * scale)};
     *reinterpret_cast<uint4*>(drow + 32) = uint4{pack_bf16x2(hi[0] * scale, hi[1] * scale), pack_bf16x2(hi[2] * scale, hi[3] * scale),
                                                  pack_bf16x2(hi[4] * scale, hi[5] * scale), pack_bf16x2(hi[6] * scale, hi[7] * scale)};
+}
+
+// the reduction as its own launch: grid (tiles, nh, B), 256 threads
+__global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int Smax,
+                                                                 int nh, float scale, const float* __restrict__ rope_cos,
+                                                                 const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+    const int head = blockIdx.y, b = blockIdx.z;
+    const SeqView sv(vl, b, head, Smax, nh);
+    dq_reduce_tile(dq_part, dqkv, blockIdx.x, head, b, threadIdx.x, sv, Smax, nh, scale, rope_cos, rope_sin, pos_batch_stride);
 }
 
 // ---- fused ----------------------------------------------------------------------------------------------------------------------
