@@ -269,7 +269,7 @@ int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R,
 // gemm8p.hip: the same tile on the half-tile ring ("8-phase" schedule); CM3P_ERR_INVALID = shape / layout not covered
 int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk,
-                         int64_t c_split_stride, hipStream_t s, RopeArgs rope);
+                         int64_t c_split_stride, hipStream_t s, RopeArgs rope, BatchArgs bt = BatchArgs{}, int batch = 0);
 
 // Development switch (read per call so that one process can A/B): CM3P_GEMM_IMPL=256 keeps the r01 kernel for every big shape.
 static inline bool use_8p() {
@@ -394,6 +394,18 @@ int cm3p_gemm_bf16_batched(const void* A, const void* B, void* C, const void* R,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const BatchArgs bt{stride_a, stride_b, stride_c, stride_r, static_cast<const uint16_t*>(R), alpha, beta};
     int rc;
+    // enough 256 x 256 tiles to occupy the chip (the 768- to 2304-wide weight groups of the Muon step: 198 to 1188): the half-tile
+    // ring kernel, one work item per (matrix, tile); everything else (and what it does not cover) on the 128 x 128 kernel
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
+    const bool filled = M * N * batch * 10 >= tiles256 * 65536 * 7;  // (edge tiles compute their padding: [520 x 264] x 30 ran at 0.59 of the small kernel)
+    if (tiles256 >= 128 && filled && K % 64 == 0 && M % 8 == 0 && (a_kc || !b_kc) && use_8p()) {
+        rc = cm3p_gemm8p_dispatch(A, B, C, nullptr, M, N, K, lda, ldb, ldc, a_kc, b_kc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
+        if (rc == CM3P_OK) {
+            CM3P_LAUNCH_CHECK();
+            return CM3P_OK;
+        }
+        if (rc != CM3P_ERR_INVALID) return rc;
+    }
     if (a_kc && b_kc) rc = launch<true, true>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
     else if (a_kc) rc = launch<true, false>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);
     else if (b_kc) rc = launch<false, true>(A, B, C, nullptr, M, N, K, lda, ldb, ldc, CM3P_EPI_BF16_AXPBY, 1, K, 0, s, RopeArgs{}, bt, batch);

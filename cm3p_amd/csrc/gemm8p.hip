@@ -160,7 +160,7 @@ template <bool A_KC, bool B_KC, int EPI, bool REBAL>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
                                                         const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                         int64_t ldc, int tiles_n, int ntiles, int total, int64_t kchunk,
-                                                        int64_t c_split_stride, RopeArgs rope) {
+                                                        int64_t c_split_stride, RopeArgs rope, BatchArgs bt, int batched) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, lane_ = lane;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,10 +191,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         int64_t m0, n0;
         int z;
         decode(v, m0, n0, z);
-        const int64_t kbeg = (int64_t)z * kchunk;
+        // z: the k-split of a plain GEMM, or (batched) the matrix of a strided batch
+        const int64_t kbeg = batched ? 0 : (int64_t)z * kchunk;
         snk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
-        oa.setup(A, lda, m0, M, kbeg, wid, lane);
-        ob.setup(B, ldb, n0, N, kbeg, wid, lane);
+        oa.setup(A + (batched ? z * bt.a_stride : 0), lda, m0, M, kbeg, wid, lane);
+        ob.setup(B + (batched ? z * bt.b_stride : 0), ldb, n0, N, kbeg, wid, lane);
     };
     auto stream_advance = [&]() {
         sah[0] = oa.p[1][0];
@@ -434,6 +435,49 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x0), "v"(x1));
                 }
             }
+        } else if constexpr (EPI == CM3P_EPI_BF16_AXPBY) {
+            // C_z = bf16(alpha * acc + beta * R_z), R bf16 with C's layout (the Newton-Schulz polynomial steps of the Muon update):
+            // the fp32 rows of the exchange below, combined in fp32 and rounded once (the arithmetic of gemm.hip's small-tile kernel)
+            char* Cb = reinterpret_cast<char*>(static_cast<uint16_t*>(Cv) + (int64_t)z * bt.c_stride + mw * ldc + nw);
+            const char* Rb = reinterpret_cast<const char*>(bt.Rb + (int64_t)z * bt.r_stride + mw * ldc + nw);
+            const uint32_t ldcb = (uint32_t)ldc * 2;
+            const int lrow = lane >> 4, lch = lane & 15;
+            const uint32_t loff = (uint32_t)lrow * ldcb + lch * 8;
+            const bool col_ok = FULL || nw + lch * 4 < N;
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                uint2 r[4];
+                if (bt.Rb) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = i4 * 16 + u * 4;
+                        r[u] = (FULL || (col_ok && mw + row + lrow < M)) ? *reinterpret_cast<const uint2*>(Rb + loff + (uint32_t)row * ldcb) : uint2{0u, 0u};
+                    }
+                }
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const int row = lane & 15, ch = j4 * 4 + (lane >> 4);
+                    *reinterpret_cast<f32x4*>(ebuf + row * 256 + ((ch ^ row) << 4)) = acc[i4][j4];
+                }
+                G8P_LANE_XCHG_FENCE();
+                f32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = u * 4 + lrow;
+                    x[u] = *reinterpret_cast<const f32x4*>(ebuf + row * 256 + ((lch ^ row) << 4));
+                }
+                G8P_LANE_XCHG_FENCE();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 v = x[u];
+                    v *= bt.alpha;
+                    if (bt.Rb) v += bt.beta * f32x4{bf16lo(r[u].x), bf16hi(r[u].x), bf16lo(r[u].y), bf16hi(r[u].y)};
+                    const int row = i4 * 16 + u * 4;
+                    if (FULL || (col_ok && mw + row + lrow < M))
+                        G8P_GLOBAL(*reinterpret_cast<uint2*>(Cb + loff + (uint32_t)row * ldcb) = (uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}));
+                    if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(v));
+                }
+            }
         } else {
             char* Cb = reinterpret_cast<char*>(static_cast<float*>(Cv) + (int64_t)z * c_split_stride + mw * ldc + nw);
             const char* Rb = reinterpret_cast<const char*>(R + mw * ldc + nw);
@@ -500,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
         int64_t m0, n0;
         int z;
         decode(v, m0, n0, z);
-        const int64_t kbeg = (int64_t)z * kchunk;
+        const int64_t kbeg = batched ? 0 : (int64_t)z * kchunk;
         const int nk = (int)((min(K, kbeg + kchunk) - kbeg) / 64);
         if constexpr (REBAL) {  // nk even (checked by the dispatcher): the register sets swap roles every k-tile
             ktile(par, std::true_type{}, fbP, fbQ);
@@ -526,9 +570,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
 
 template <bool A_KC, bool B_KC, bool REBAL>
 int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-             int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
+             int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope, BatchArgs bt,
+             int batch) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
-    const int ntiles = tiles_m * tiles_n, total = ntiles * splits;
+    const int ntiles = tiles_m * tiles_n, total = ntiles * (batch > 0 ? batch : splits);
     static int num_cu = 0;
     if (num_cu == 0) {
         int dev = 0;
@@ -545,7 +590,7 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
                 return CM3P_ERR_LAUNCH;                                                                                           \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm8p_kernel<A_KC, B_KC, E, REBAL><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
+        gemm8p_kernel<A_KC, B_KC, E, REBAL><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope, bt, batch > 0 ? 1 : 0); \
     }
     switch (epi) {
         case CM3P_EPI_BF16: CM3P_G8P(CM3P_EPI_BF16) break;
@@ -563,6 +608,12 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
                 break;
             }
             return CM3P_ERR_INVALID;
+        case CM3P_EPI_BF16_AXPBY:
+            if constexpr (A_KC || !B_KC) {  // (the Muon step's three layouts)
+                CM3P_G8P(CM3P_EPI_BF16_AXPBY)
+                break;
+            }
+            return CM3P_ERR_INVALID;
         default: return CM3P_ERR_INVALID;
     }
 #undef CM3P_G8P
@@ -574,7 +625,9 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
 // Internal entry used by gemm.hip; returns CM3P_ERR_INVALID for what this kernel does not cover (the caller then falls back).
 int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk, int64_t c_split_stride,
-                         hipStream_t s, RopeArgs rope) {
+                         hipStream_t s, RopeArgs rope, BatchArgs bt, int batch) {
+    // batch > 0: a strided batch of `batch` matrices (the work item's z is the matrix instead of the k-split), bf16 a x + b y epilogue
+    if ((batch > 0) != (epi == CM3P_EPI_BF16_AXPBY) || (batch > 0 && (splits != 1 || kchunk != K))) return CM3P_ERR_INVALID;
     if (M % 8 != 0 || N % 8 != 0 || K % 64 != 0 || kchunk % 64 != 0) return CM3P_ERR_INVALID;
     if (lda * 2 * 8 >= (int64_t(1) << 31) || ldb * 2 * 8 >= (int64_t(1) << 31)) return CM3P_ERR_INVALID;  // 32-bit lane offsets
     const uint16_t* a = static_cast<const uint16_t*>(A);
@@ -584,8 +637,8 @@ int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, 
     static const bool no_rebal = [] { const char* e = getenv("CM3P_G8P_REBAL"); return e && e[0] == '0'; }();
     const bool rebal = !no_rebal && (kchunk / 64) % 2 == 0 && (splits == 1 ? (K / 64) % 2 == 0 : (last > 0 && (last / 64) % 2 == 0));
 #define CM3P_G8P_GO(AK, BK)                                                                                                      \
-    return rebal ? launch8p<AK, BK, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope)        \
-                 : launch8p<AK, BK, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope)
+    return rebal ? launch8p<AK, BK, true>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope, bt, batch)  \
+                 : launch8p<AK, BK, false>(a, b, C, R, M, N, K, lda, ldb, ldc, epi, splits, kchunk, c_split_stride, s, rope, bt, batch)
     if (a_kc && b_kc) CM3P_G8P_GO(true, true);
     if (a_kc) CM3P_G8P_GO(true, false);
     if (b_kc) CM3P_G8P_GO(false, true);

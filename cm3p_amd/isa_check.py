@@ -64,9 +64,11 @@ def check_gemm8p(isa: str):
     registers in every accumulating MFMA."""
     no_scratch(isa, "gemm8p.hip")
     bodies = kernel_bodies(isa, "gemm8p_kernel")
-    _need(len(bodies) >= 24, f"gemm8p.hip: {len(bodies)} kernel instances found")
+    _need(len(bodies) >= 34, f"gemm8p.hip: {len(bodies)} kernel instances found")
     for sym, body in bodies.items():
-        rebal = sym.endswith("ELb1EEEvPKtS2_PvPKflllllliiill8RopeArgs")
+        m = re.search(r"gemm8p_kernelILb[01]ELb[01]ELi\d+ELb([01])EEEv", sym)
+        _need(m, f"{sym}: template arguments not recognised")
+        rebal = m.group(1) == "1"
         n = 2 if rebal else 1
         ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_16x16x32_bf16") == 64 * n]
         _need(ring, f"{sym}: steady-state k-loop ({64 * n} MFMAs) not found")

@@ -109,9 +109,11 @@ def _bf16_mm_ref(a, b):
 
 
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("dims", [(3, 40, 24, 56), (2, 128, 256, 64), (1, 200, 136, 72)])
+@pytest.mark.parametrize("dims", [(3, 40, 24, 56), (2, 128, 256, 64), (1, 200, 136, 72), (16, 768, 1152, 192), (34, 504, 488, 128)])
 def test_batched_gemm_axpby(form, dims):
-    """cm3p_gemm_bf16_batched against fp32 matmul of the same bf16 operands: |err| <= bf16 rounding of the result."""
+    """cm3p_gemm_bf16_batched against fp32 matmul of the same bf16 operands: |err| <= bf16 rounding of the result.  The last two
+    cases have >= 128 tiles of 256 x 256 and go to the half-tile-ring kernel (gemm8p.hip, one work item per matrix and tile;
+    partial edge tiles, an odd and an even k-tile count); the rest stay on the 128 x 128 kernel."""
     from cm3p_amd import _lib
 
     n, M, N, K = dims

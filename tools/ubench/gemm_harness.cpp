@@ -4,6 +4,7 @@
 // near out-of-bounds access corrupts a guard (reported) instead of faulting the GPU.
 //   hipcc --offload-arch=gfx950 -O2 -o tools/ubench/gemm_harness tools/ubench/gemm_harness.cpp -ldl
 //   tools/ubench/gemm_harness [check] [time]        (run from the repository root)
+//   tools/ubench/gemm_harness batched               (the strided-batch a x + b y GEMMs of the Muon step: 128-tile kernel vs gemm8p.hip)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,6 +21,9 @@
 typedef int (*gemm_fn)(const void*, const void*, void*, const float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int,
                        float*, void*);
 static gemm_fn cm3p_gemm_bf16;
+typedef int (*bgemm_fn)(const void*, const void*, void*, const void*, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                        int64_t, int64_t, int, int, float, float, void*);
+static bgemm_fn cm3p_gemm_bf16_batched;
 
 #define CK(x)                                                                  \
     do {                                                                       \
@@ -106,6 +110,72 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         printf("ran 20 launches of [%ld x %ld x %ld]\n", (long)M, (long)N, (long)K);
         return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "batched")) {
+        const char* libpathb = getenv("CM3P_HIP_LIB") ? getenv("CM3P_HIP_LIB") : "cm3p_amd/csrc/libcm3p_hip.so";
+        void* libb = dlopen(libpathb, RTLD_NOW);
+        if (!libb) return 2;
+        cm3p_gemm_bf16_batched = (bgemm_fn)dlsym(libb, "cm3p_gemm_bf16_batched");
+        unsigned long long* d_cnt;
+        CK(hipMalloc(&d_cnt, 8));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        // (n, M, N, K, lda, ldb, a_kc, b_kc, with R): the three products of a Newton-Schulz step for the [2304, 768] x 44, [768, 768] x 22,
+        // [1152, 768] x 22 ([768, 1152] stored) groups; operands in one buffer each, matrix strides = their sizes
+        struct T { int n; int64_t M, N, K; int a_kc, b_kc, r; const char* name; };
+        const T ts[] = {{44, 768, 768, 2304, 0, 0, 0, "A = X^T X   [2304 x 768] x 44 (ks,ks)"},
+                        {44, 768, 768, 768, 1, 1, 1, "B = bA + cAA [768 x 768] x 44 (kc,kc)"},
+                        {44, 2304, 768, 768, 1, 1, 1, "X' = aX + XB [2304 x 768] x 44 (kc,kc)"},
+                        {22, 768, 768, 768, 1, 1, 0, "A = X X^T   [768 x 768] x 22 (kc,kc)"},
+                        {22, 768, 768, 768, 1, 0, 1, "X' = aX + BX [768 x 768] x 22 (kc,ks)"},
+                        {22, 768, 768, 1152, 1, 1, 0, "A = X X^T   [768 x 1152] x 22 (kc,kc)"},
+                        {22, 768, 1152, 768, 1, 0, 1, "X' = aX + BX [768 x 1152] x 22 (kc,ks)"},
+                        {30, 520, 264, 192, 1, 1, 1, "edge tiles  [520 x 264 x 192] x 30 (kc,kc)"},
+                        {130, 256, 256, 128, 0, 0, 1, "many small  [256 x 256 x 128] x 130 (ks,ks)"}};
+        int badb = 0;
+        for (const T& t : ts) {
+            const int64_t lda = t.a_kc ? t.K : t.M, ldb = t.b_kc ? t.K : t.N;
+            const int64_t sa = t.M * t.K, sb = t.N * t.K, sc = t.M * t.N;
+            Guarded A, B, R, C0, C1;
+            A.alloc(t.n * sa * 2); B.alloc(t.n * sb * 2); R.alloc(t.n * sc * 2); C0.alloc(t.n * sc * 2); C1.alloc(t.n * sc * 2);
+            fill_bf16<<<1024, 256>>>((uint16_t*)A.p(), t.n * sa, 1u, 1.f);
+            fill_bf16<<<1024, 256>>>((uint16_t*)B.p(), t.n * sb, 2u, 1.f);
+            fill_bf16<<<1024, 256>>>((uint16_t*)R.p(), t.n * sc, 3u, 1.f);
+            CK(hipDeviceSynchronize());
+            std::vector<float> ms[2];
+            int rc[2] = {0, 0};
+            for (int round = 0; round < 5; ++round)
+                for (int which = 0; which < 2; ++which) {
+                    impl(which ? "8p" : "256");
+                    void* C = which ? C1.p() : C0.p();
+                    const void* r = t.r ? R.p() : nullptr;
+                    for (int i = 0; i < 2; ++i)
+                        rc[which] |= cm3p_gemm_bf16_batched(A.p(), B.p(), C, r, t.n, t.M, t.N, t.K, lda, ldb, t.N, sa, sb, sc, sc, t.a_kc, t.b_kc, 2.0315f, -4.775f, nullptr);
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 10; ++i)
+                        cm3p_gemm_bf16_batched(A.p(), B.p(), C, r, t.n, t.M, t.N, t.K, lda, ldb, t.N, sa, sb, sc, sc, t.a_kc, t.b_kc, 2.0315f, -4.775f, nullptr);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float m;
+                    CK(hipEventElapsedTime(&m, e0, e1));
+                    ms[which].push_back(m / 10);
+                }
+            for (auto& v : ms) std::sort(v.begin(), v.end());
+            CK(hipMemset(d_cnt, 0, 8));
+            count_diff_u32<<<1024, 256>>>((const uint32_t*)C0.p(), (const uint32_t*)C1.p(), (size_t)t.n * sc / 2, d_cnt);
+            unsigned long long nd;
+            CK(hipMemcpy(&nd, d_cnt, 8, hipMemcpyDeviceToHost));
+            const unsigned long long g = C1.guards_touched(d_cnt);
+            const double fl = 2.0 * t.n * t.M * t.N * t.K;
+            const bool fail = nd || g || rc[0] || rc[1];
+            printf("%-46s 128-tile %7.3f ms %7.1f TF/s | 8p %7.3f ms %7.1f TF/s | x%.2f | differing dwords %llu, guards %llu, rc %d %d %s\n", t.name,
+                   ms[0][2], fl / ms[0][2] / 1e9, ms[1][2], fl / ms[1][2] / 1e9, ms[0][2] / ms[1][2], nd, g, rc[0], rc[1], fail ? "FAIL" : "OK");
+            fflush(stdout);
+            badb += fail;
+            A.release(); B.release(); R.release(); C0.release(); C1.release();
+        }
+        return badb ? 1 : 0;
     }
     for (int i = 1; i < argc; ++i) {
         do_check |= !strcmp(argv[i], "check");
