@@ -18,6 +18,7 @@ activations are bf16 (what HF Trainer's bf16 autocast gives the reference's nn.L
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -92,12 +93,33 @@ def _bf16_weight(w: Tensor) -> Tensor:
     return K.cast_bf16(w.contiguous())
 
 
+_eval_weights: dict = {}  # id(parameter) -> (weakref to it, its _version, its data_ptr, bf16 copy): forward-only calls
+
+
+def _bf16_weight_cached(w: Tensor) -> Tensor:
+    """Forward-only calls (no backward will follow: evaluation, embedding extraction) reuse the bf16 copy of a master weight for
+    as long as the weight is the same object with the same version counter and storage - every in-place update (optimizer step,
+    load_state_dict) bumps the counter, `p.data = ...` changes the address.  A training step re-casts every weight once anyway."""
+    hit = _eval_weights.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+        return hit[3]
+    wb = _bf16_weight(w)
+    if wb.data_ptr() != w.data_ptr():  # (a bf16 master weight is its own operand: nothing to keep)
+        if len(_eval_weights) > 4096:  # dead entries of models that are gone
+            for k in [k for k, v in _eval_weights.items() if v[0]() is None]:
+                del _eval_weights[k]
+        _eval_weights[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), wb)
+    return wb
+
+
 def _bf16_weight_pair(w: Tensor, want_t: bool):
     """-> (bf16 W [out, in], bf16 W^T [in, out] or None).  The transpose feeds the input-gradient GEMM (dx = dy W) with the
     contraction index contiguous in both operands; it is made in the same pass as the cast when a backward will follow and the
     extents allow it (multiples of 8), otherwise dgrad reads W itself (k-strided operand, same result)."""
+    if not want_t:
+        return _bf16_weight_cached(w), None
     w = w.detach()
-    if want_t and w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+    if w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
         return K.cast_bf16_with_transpose(w.contiguous())
     return _bf16_weight(w), None
 

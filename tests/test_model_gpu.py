@@ -132,6 +132,39 @@ def test_bf16_model_and_eval_mode():
     assert g.dtype == torch.bfloat16 and torch.isfinite(g.float()).all()
 
 
+def test_forward_only_calls_reuse_bf16_weights_until_the_weight_changes():
+    """No-grad calls keep the bf16 copies of the master weights (encoder._bf16_weight_cached) instead of re-casting all of them
+    per call; an in-place update (what an optimizer step or load_state_dict does) or a swapped `.data` must be seen at once."""
+    from cm3p_amd import encoder as E
+
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name).eval()
+    E._eval_weights.clear()
+    with torch.no_grad():
+        a = model(**_inputs(blob)).logits_per_metadata.clone()
+        n_cached = len(E._eval_weights)
+        b = model(**_inputs(blob)).logits_per_metadata.clone()
+        assert n_cached > 0 and len(E._eval_weights) == n_cached and torch.equal(a, b)  # second call: every weight was a hit
+        w = model.beatmap_model.encoder.layers[1].attn.Wqkv.weight
+        w.mul_(1.5)  # version counter moves
+        c = model(**_inputs(blob)).logits_per_metadata.clone()
+        E._eval_weights.clear()
+        c_fresh = model(**_inputs(blob)).logits_per_metadata.clone()
+        assert torch.equal(c, c_fresh) and not torch.equal(c, a)
+        w2 = model.metadata_model.encoder.layers[0].mlp.Wi.weight
+        w2.data = w2.data * 0.5  # new storage, same version counter
+        d = model(**_inputs(blob)).logits_per_metadata.clone()
+        E._eval_weights.clear()
+        d_fresh = model(**_inputs(blob)).logits_per_metadata.clone()
+        assert torch.equal(d, d_fresh) and not torch.equal(d, c)
+    # a training call does not read the cache (its casts also make the transposed copies) and is unaffected by it
+    model.train()
+    out = model(**_inputs(blob))
+    out.loss.backward()
+    assert torch.isfinite(out.loss)
+
+
 def test_inputs_on_cpu_are_refused():
     from cm3p_amd import CM3PConfig, CM3PModel
 
