@@ -581,7 +581,12 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
         if (num_cu <= 0) num_cu = 256;
     }
-    const dim3 grid(total < num_cu ? total : num_cu);
+    int want = num_cu;
+    if (const char* e = getenv("CM3P_G8P_GRID")) {  // development switch: leave CUs to a kernel on another stream (tools/overlap_ab.py)
+        const int g = atoi(e);
+        if (g > 0 && g < want) want = g;
+    }
+    const dim3 grid(total < want ? total : want);
 #define CM3P_G8P(E)                                                                                                               \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \

@@ -5,6 +5,8 @@
 //   TF:models/modernbert/modeling_modernbert.py:61,64-71   embeddings: LayerNorm(tok_embeddings(ids)), no bias
 //   TF:models/modernbert/modeling_modernbert.py:309-314,420 attn_norm / mlp_norm / final_norm = nn.LayerNorm(H, eps, bias=False)
 //   ref:cm3p/modeling_cm3p.py:592,603-605                   embedding lookup and the audio-embedding scatter
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -358,7 +360,13 @@ inline int ln_grid(int64_t rows, int cap = 2048) {
     return (int)blocks;
 }
 // (r03 sweep at C2: 768 and 1024 workgroups 0.29 ms, 512 0.335, 1280 - a fifth workgroup per CU that 98 VGPRs do not admit - 0.36, 2048 0.32)
-inline int ln_bwd_grid(int64_t rows) { return ln_grid(rows, 1024); }
+inline int ln_bwd_grid(int64_t rows) {
+    if (const char* e = getenv("CM3P_LN_BWD_CAP")) {  // development switch (tools/overlap_ab.py)
+        const int g = atoi(e);
+        if (g > 0) return ln_grid(rows, g);
+    }
+    return ln_grid(rows, 1024);
+}
 
 }  // namespace
 
