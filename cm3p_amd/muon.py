@@ -196,25 +196,53 @@ class Muon(torch.optim.Optimizer):
                 table.extend(col)
         dev_table = torch.tensor(table, dtype=torch.int64).to(device, non_blocking=True)
         base = dev_table.data_ptr()
+
+        # Groups whose GEMMs fill the chip (the 256 x 256 ring kernel's rule in csrc/gemm.hip) run on the caller's stream; the small
+        # ones (metadata tower, projections: a few workgroups per launch, ~110 launches) and the AdamW tensors run beside them on a
+        # second stream - the groups are independent, the small launches fit into the big GEMMs' partial last waves.  Joined below.
+        def fills_chip(key, n):
+            s_ = min(_up8(key[0]), _up8(key[1]))
+            return n * ((s_ + 255) // 256) ** 2 >= 128
+
+        main_s = torch.cuda.current_stream(device)
+        side_s = self._side_stream(device)
+        side_s.wait_stream(main_s)
+        ordered = sorted(shape_groups.items(), key=lambda kv: not fills_chip(kv[0], len(kv[1])))
+        for key, items in ordered:
+            with torch.cuda.stream(main_s if fills_chip(key, len(items)) else side_s):
+                self._muon_group(gi, group, key, items, layout, base, device, lr, momentum)
+        with torch.cuda.stream(side_s):
+            self._adamw_tensors(group, adamw_by_step, layout, base, lr)
+        main_s.wait_stream(side_s)
+        # dev_table must outlive the launches above: they are stream-ordered (the second stream is joined) before any later reuse of
+        # its memory by torch's caching allocator on the caller's stream.
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device)
+        return streams[device]
+
+    def _muon_group(self, gi, group, key, items, layout, base, device, lr, momentum):
         st = stream()
+        rows, cols = key
+        n = len(items)
+        ws = self._workspace((gi, key), n, rows, cols, device)
+        aligned = all(it[1].data_ptr() % 16 == 0 and it[2].data_ptr() % 16 == 0 for it in items)
+        numel = rows * cols
+        call("cm3p_muon_momentum", base + 8 * layout[(key, "g")], base + 8 * layout[(key, "buf")], ws.X.data_ptr(),
+             ws.partials.data_ptr(), n, rows, cols, ws.cp, ws.x_stride, float(momentum), int(bool(group["nesterov"])),
+             int(aligned), st, tag="muon_momentum", work=14.0 * n * numel)
+        call("cm3p_muon_normalize", ws.X.data_ptr(), ws.partials.data_ptr(), n, rows, cols, ws.x_stride, NS_EPS, st,
+             tag="muon_normalize", work=4.0 * n * ws.x_stride)
+        out = newton_schulz_batched(ws, int(group["ns_steps"]))
+        call("cm3p_muon_apply", base + 8 * layout[(key, "p")], out.data_ptr(), n, rows, cols, ws.cp, ws.x_stride,
+             float(max(1, rows / cols) ** 0.5), float(-lr), st, tag="muon_apply", work=10.0 * n * numel)
+        if out is ws.X2:  # keep "X holds the next step's input, X2 is scratch" (odd iteration counts swap them)
+            ws.X, ws.X2 = ws.X2, ws.X
 
-        for key, items in shape_groups.items():
-            rows, cols = key
-            n = len(items)
-            ws = self._workspace((gi, key), n, rows, cols, device)
-            aligned = all(it[1].data_ptr() % 16 == 0 and it[2].data_ptr() % 16 == 0 for it in items)
-            numel = rows * cols
-            call("cm3p_muon_momentum", base + 8 * layout[(key, "g")], base + 8 * layout[(key, "buf")], ws.X.data_ptr(),
-                 ws.partials.data_ptr(), n, rows, cols, ws.cp, ws.x_stride, float(momentum), int(bool(group["nesterov"])),
-                 int(aligned), st, tag="muon_momentum", work=14.0 * n * numel)
-            call("cm3p_muon_normalize", ws.X.data_ptr(), ws.partials.data_ptr(), n, rows, cols, ws.x_stride, NS_EPS, st,
-                 tag="muon_normalize", work=4.0 * n * ws.x_stride)
-            out = newton_schulz_batched(ws, int(group["ns_steps"]))
-            call("cm3p_muon_apply", base + 8 * layout[(key, "p")], out.data_ptr(), n, rows, cols, ws.cp, ws.x_stride,
-                 float(max(1, rows / cols) ** 0.5), float(-lr), st, tag="muon_apply", work=10.0 * n * numel)
-            if out is ws.X2:  # keep "X holds the next step's input, X2 is scratch" (odd iteration counts swap them)
-                ws.X, ws.X2 = ws.X2, ws.X
-
+    def _adamw_tensors(self, group, adamw_by_step, layout, base, lr):
+        st = stream()
         b1, b2 = group["adamw_betas"]
         adamw_lr = lr * group["adamw_lr_ratio"]
         for t, items in adamw_by_step.items():
@@ -224,8 +252,6 @@ class Muon(torch.optim.Optimizer):
                  len(items), max(p.numel() for p, _, _ in items), float(1 - b1), float(1 - b2), float(group["adamw_eps"]),
                  float(1 - adamw_lr * group["adamw_wd"]), float(-lr / scale), st, tag="adamw_multi",
                  work=28.0 * sum(p.numel() for p, _, _ in items))
-        # dev_table must outlive the launches above: they are stream-ordered before any later reuse of its memory by
-        # torch's caching allocator on this same stream.
 
 
 __all__ = ["Muon", "newton_schulz_batched"]
