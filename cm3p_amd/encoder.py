@@ -94,6 +94,7 @@ def _bf16_weight(w: Tensor) -> Tensor:
 
 
 _eval_weights: dict = {}  # id(parameter) -> (weakref to it, its _version, its data_ptr, bf16 copy): forward-only calls
+K._other_caches.append(_eval_weights)  # (kernels.release_workspaces() empties it)
 
 
 def _bf16_weight_cached(w: Tensor) -> Tensor:

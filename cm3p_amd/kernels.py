@@ -241,10 +241,16 @@ ATTN_BWD_FUSED_PREP, ATTN_BWD_FUSED_MAIN, ATTN_BWD_FUSED_REDUCE = 1, 2, 4  # sta
 _fused_ws: dict = {}  # (device index, stream) -> byte tensor: the fused backward's workspace, grown on demand, shared by all layers
 
 
+_other_caches: list = []  # dicts other modules keep device memory in (encoder.py: the forward-only bf16 weight copies)
+
+
 def release_workspaces() -> None:
-    """Drop the cached workspaces of the fused attention backward (3.3 GB at C2, 6.5 GB at C4 per device and stream): call it
-    between jobs of different sequence lengths if the memory matters; the next backward allocates what it needs."""
+    """Drop the cached workspaces of the fused attention backward (3.3 GB at C2, 6.5 GB at C4 per device and stream) and the bf16
+    weight copies kept for forward-only calls: call it between jobs of different sequence lengths if the memory matters; the next
+    call allocates what it needs."""
     _fused_ws.clear()
+    for c in _other_caches:
+        c.clear()
 
 
 def attn_bwd_fused_enabled() -> bool:
