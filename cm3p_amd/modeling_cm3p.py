@@ -13,6 +13,7 @@ but they raise NotImplementedError when constructed.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Optional
 
@@ -609,6 +610,27 @@ class CM3PBeatmapModel(CM3PPreTrainedModel):
 
 
 # ----------------------------------------------------------------------------------------------- the dual tower
+_tower_streams: dict = {}  # device -> the stream the metadata tower runs on beside the beatmap tower
+
+
+def _tower_stream(device) -> "torch.cuda.Stream":
+    st = _tower_streams.get(device)
+    if st is None:
+        st = _tower_streams[device] = torch.cuda.Stream(device)
+    return st
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors_of(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_of(o)
+
+
 class CM3PModel(CM3PPreTrainedModel):
     config_class = CM3PConfig
 
@@ -638,6 +660,16 @@ class CM3PModel(CM3PPreTrainedModel):
         self.gather_negatives = False
         self.unpad_inputs = None  # True / False overrides the reference's rule (unpad iff attn_implementation is flash_attention_2)
         self.post_init()
+
+    def _overlap_towers(self, input_ids, metadata_ids) -> bool:
+        """Run the metadata tower on a second stream beside the beatmap tower?  (CM3P_TOWER_OVERLAP=0 switches it off.)"""
+        if input_ids is None or metadata_ids is None or not metadata_ids.is_cuda or self.gather_negatives:
+            return False
+        if os.environ.get("CM3P_TOWER_OVERLAP", "1") == "0":
+            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            return False
+        return True
 
     def get_metadata_features(self, input_ids=None, output_attentions=None, output_hidden_states=None) -> Tensor:
         out = self.metadata_model(input_ids=input_ids)
@@ -684,6 +716,25 @@ class CM3PModel(CM3PPreTrainedModel):
         logits_per_beatmap = logits_per_metadata = None
         loss = 0 if return_loss else None
 
+        def run_metadata():
+            mo = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
+                                     output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+            p = mo.pooler_output
+            me = _L2NormFn.apply(_ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight))
+            return mo, me.view(*p.shape[:-1], -1)
+
+        # The two towers do not meet before the logits.  On one GPU the metadata tower (a few hundred launches of a few workgroups:
+        # 8192 tokens at C2) runs on a second stream BESIDE the beatmap tower instead of after it; autograd runs each node's
+        # backward on its forward stream and orders the gradients across streams, so the backward overlaps the same way.
+        # Not with gathered negatives / more than one rank (DDP's bucket hooks take the stream of the last gradient of a bucket).
+        side = None
+        if self._overlap_towers(input_ids, metadata_ids):
+            main = torch.cuda.current_stream(metadata_ids.device)
+            side = _tower_stream(metadata_ids.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                metadata_outputs, metadata_embeds = run_metadata()
+
         if input_ids is not None:
             if self.unpad_inputs is not None or getattr(self.config, "_attn_implementation", None) == "flash_attention_2":
                 self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
@@ -704,13 +755,14 @@ class CM3PModel(CM3PPreTrainedModel):
 
                     warn_variations_stay_local()
 
-        if metadata_ids is not None:
+        if side is not None:
+            # join: everything the caller (and the logits) will read was produced on `side`; its memory belongs to that stream's pool
+            main.wait_stream(side)
+            for t in _tensors_of((metadata_embeds, dict(metadata_outputs))):
+                t.record_stream(main)
+        elif metadata_ids is not None:
             try:
-                metadata_outputs = self.metadata_model(input_ids=metadata_ids, attention_mask=metadata_attention_mask,
-                                                       output_attentions=output_attentions, output_hidden_states=output_hidden_states)
-                p = metadata_outputs.pooler_output
-                me = _L2NormFn.apply(_ProjectFn.apply(p.reshape(-1, p.size(-1)), self.metadata_projection.weight))
-                metadata_embeds = me.view(*p.shape[:-1], -1)
+                metadata_outputs, metadata_embeds = run_metadata()
             except BaseException:
                 if beatmap_pending is not None:  # never leave a collective un-joined behind an exception
                     beatmap_pending.wait()
