@@ -132,6 +132,33 @@ def test_bf16_model_and_eval_mode():
     assert g.dtype == torch.bfloat16 and torch.isfinite(g.float()).all()
 
 
+def test_metadata_tower_on_its_own_stream_gives_the_same_step(monkeypatch):
+    """On one rank the metadata tower runs on a second stream beside the beatmap tower (CM3PModel._overlap_towers); the same
+    kernels on the same data in another stream order: loss and every gradient bit-identical to the single-stream run, also over
+    several steps that free and reuse the second stream's memory."""
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CM3P_TOWER_OVERLAP", mode)
+        model = _build(name)
+        assert model._overlap_towers(_inputs(blob)["input_ids"], _inputs(blob)["metadata_ids"]) == (mode == "1")
+        for _ in range(3):
+            for p_ in model.parameters():
+                p_.grad = None
+            out = model(**_inputs(blob))
+            out.loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (out.loss.detach().clone(), {k: p_.grad.clone() for k, p_ in model.named_parameters() if p_.grad is not None},
+                     out.metadata_embeds.detach().clone())
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][2], res["1"][2])
+    assert res["0"][1].keys() == res["1"][1].keys()
+    for k in res["0"][1]:
+        if "tok_embeddings" in k:  # (the embedding gradient is an atomic scatter-add: not ordered in either mode)
+            continue
+        assert torch.equal(res["0"][1][k], res["1"][1][k]), k
+
+
 def test_forward_only_calls_reuse_bf16_weights_until_the_weight_changes():
     """No-grad calls keep the bf16 copies of the master weights (encoder._bf16_weight_cached) instead of re-casting all of them
     per call; an in-place update (what an optimizer step or load_state_dict does) or a swapped `.data` must be seen at once."""
