@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -44,6 +44,7 @@ SIGNATURES = {
     "cm3p_attn_probs": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _I, _P],
     "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
+    "cm3p_gemm_geglu": [_P, _P, _P, _L, _L, _L, _P],
     "cm3p_geglu_bwd": [_P, _P, _P, _L, _I, _P],
     "cm3p_gelu_fwd": [_P, _P, _L, _P],
     "cm3p_gelu_bwd": [_P, _P, _P, _L, _P],

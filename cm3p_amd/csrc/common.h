@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define CM3P_EPI_BF16_ROPE 3   // internal: bf16 output with rotary embedding applied to the leading columns
 #define CM3P_EPI_BF16_AXPBY 4  // internal: bf16 output = alpha * acc + beta * Rb (cm3p_gemm_bf16_batched)
 // 5 = CM3P_EPI_F32_BIAS (public, include/cm3p_hip.h)
+#define CM3P_EPI_BF16_GEGLU 6  // internal (cm3p_gemm_geglu): every 64 output columns are [32 h | 32 g]; stores gelu_erf(h) * g, 32 columns
 
 // Strided-batch offsets (elements) and the AXPBY epilogue operands of the 128 x 128 GEMM kernel.
 struct BatchArgs {

@@ -382,6 +382,18 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
     return CM3P_OK;
 }
 
+int cm3p_gemm_geglu(const void* x, const void* w_interleaved, void* a, int64_t T, int64_t I, int64_t K, void* stream) {
+    CM3P_REQUIRE(x && w_interleaved && a && T > 0 && I > 0 && K > 0);
+    CM3P_REQUIRE(cm3p_aligned16(x) && cm3p_aligned16(w_interleaved) && cm3p_aligned16(a));
+    // the half-tile-ring kernel's shapes only (the caller keeps the two-kernel path for everything else)
+    CM3P_REQUIRE(K % 64 == 0 && I % 32 == 0 && T % 8 == 0 && tiles_of(T, 2 * I, 256) >= 200);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = cm3p_gemm8p_dispatch(x, w_interleaved, a, nullptr, T, 2 * I, K, K, K, I, 1, 1, CM3P_EPI_BF16_GEGLU, 1, K, 0, s, RopeArgs{});
+    if (rc != CM3P_OK) return rc;
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
 int cm3p_gemm_bf16_batched(const void* A, const void* B, void* C, const void* R, int batch, int64_t M, int64_t N, int64_t K,
                            int64_t lda, int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c,
                            int64_t stride_r, int a_kc, int b_kc, float alpha, float beta, void* stream) {

@@ -63,6 +63,8 @@ __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // (HIP's uint4 is a struct: arrays of it land in scratch)
 
+__device__ __forceinline__ float gelu_erf8p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }  // (elementwise.hip's, to the bit)
+
 #if CM3P_G8P_ABL & 1
 #define G8P_GLOBAL(stmt) asm volatile("" ::: "memory")
 #else
@@ -435,6 +437,35 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x0), "v"(x1));
                 }
             }
+        } else if constexpr (EPI == CM3P_EPI_BF16_GEGLU) {
+            // The Wi projection with GeGLU in its store phase (forward-only calls: nothing keeps h and g).  The weight rows were
+            // interleaved on the host so that a wave's 64 columns are [h_j .. h_j+31 | g_j .. g_j+31]: the rows are staged as bf16
+            // (the rounding the unfused path applies when it stores h and g), a lane takes 8 h and the 8 g of the same columns,
+            // and 4 lanes write a row's 64 bytes of gelu_erf(h) * g.  C is [M, N / 2] bf16, ldc its row pitch.
+            char* Cb = reinterpret_cast<char*>(static_cast<uint16_t*>(Cv) + mw * ldc + nw / 2);
+            const uint32_t ldcb = (uint32_t)ldc * 2;
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                char* eb = ebuf + (i4 & 1) * 2048;
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const f32x4 a = acc[i4][j4];
+                    const int row = lane & 15, s8 = (j4 * 4 + (lane >> 4)) ^ ((row & 7) << 1);
+                    *reinterpret_cast<uint2*>(eb + row * 128 + s8 * 8) = uint2{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w)};
+                }
+                G8P_LANE_XCHG_FENCE();
+                const int row = lane >> 2, dc = lane & 3;
+                const u32x4 xh = *reinterpret_cast<const u32x4*>(eb + row * 128 + ((dc ^ (row & 7)) << 4));
+                const u32x4 xg = *reinterpret_cast<const u32x4*>(eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4));
+                G8P_LANE_XCHG_FENCE();
+                u32x4 y;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    y[t] = pack_bf16x2(gelu_erf8p(bf16lo(xh[t])) * bf16lo(xg[t]), gelu_erf8p(bf16hi(xh[t])) * bf16hi(xg[t]));
+                if (FULL || (mw + i4 * 16 + row < M && nw + dc * 8 < N))
+                    G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16) = y);
+                if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(y));
+            }
         } else if constexpr (EPI == CM3P_EPI_BF16_AXPBY) {
             // C_z = bf16(alpha * acc + beta * R_z), R bf16 with C's layout (the Newton-Schulz polynomial steps of the Muon update):
             // the fp32 rows of the exchange below, combined in fp32 and rounded once (the arithmetic of gemm.hip's small-tile kernel)
@@ -610,6 +641,12 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
         case CM3P_EPI_F32_BIAS:
             if constexpr (A_KC && B_KC) {
                 CM3P_G8P(CM3P_EPI_F32_BIAS)
+                break;
+            }
+            return CM3P_ERR_INVALID;
+        case CM3P_EPI_BF16_GEGLU:
+            if constexpr (A_KC && B_KC) {
+                CM3P_G8P(CM3P_EPI_BF16_GEGLU)
                 break;
             }
             return CM3P_ERR_INVALID;

@@ -18,6 +18,7 @@ activations are bf16 (what HF Trainer's bf16 autocast gives the reference's nn.L
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -97,19 +98,23 @@ _eval_weights: dict = {}  # id(parameter) -> (weakref to it, its _version, its d
 K._other_caches.append(_eval_weights)  # (kernels.release_workspaces() empties it)
 
 
-def _bf16_weight_cached(w: Tensor) -> Tensor:
+def _bf16_weight_cached(w: Tensor, geglu_rows: bool = False) -> Tensor:
     """Forward-only calls (no backward will follow: evaluation, embedding extraction) reuse the bf16 copy of a master weight for
     as long as the weight is the same object with the same version counter and storage - every in-place update (optimizer step,
-    load_state_dict) bumps the counter, `p.data = ...` changes the address.  A training step re-casts every weight once anyway."""
-    hit = _eval_weights.get(id(w))
+    load_state_dict) bumps the counter, `p.data = ...` changes the address.  A training step re-casts every weight once anyway.
+    geglu_rows: the copy of a Wi weight with its rows in the order cm3p_gemm_geglu reads (kernels.geglu_interleave_index)."""
+    key = (id(w), geglu_rows)
+    hit = _eval_weights.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
         return hit[3]
     wb = _bf16_weight(w)
+    if geglu_rows:
+        wb = wb.index_select(0, K.geglu_interleave_index(w.shape[0] // 2, wb.device)).contiguous()
     if wb.data_ptr() != w.data_ptr():  # (a bf16 master weight is its own operand: nothing to keep)
         if len(_eval_weights) > 4096:  # dead entries of models that are gone
             for k in [k for k, v in _eval_weights.items() if v[0]() is None]:
                 del _eval_weights[k]
-        _eval_weights[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), wb)
+        _eval_weights[key] = (weakref.ref(w), w._version, w.data_ptr(), wb)
     return wb
 
 
@@ -155,7 +160,7 @@ def _take_from_downstream(geo: _Geometry, dy: Tensor):
 
 def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
     """One encoder layer on [T, H] rows: -> (x_out, activations needed by its backward)."""
-    w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb
+    w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb[:6]
     B, S, nh = geo.B, geo.S, geo.nh
     scale = 64 ** -0.5
     cos, sin = geo.rope[i]
@@ -174,8 +179,11 @@ def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
             geo.attn_out.append(K.attn_probs(qkv, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True))
     x_mid = K.linear_fwd(o, Wo_b, resid=x)
     _, xn2, mean_m, rstd_m = K.layernorm_fwd(x_mid, w_mn, geo.eps, False, True, want_stats)
-    h = K.linear_fwd(xn2, Wi_b)
-    g = K.geglu_fwd(h)
+    if len(wb) > 6 and wb[6] is not None:  # forward-only call: Wi and GeGLU in one kernel, h and g never exist (bit-identical a)
+        h, g = None, K.gemm_geglu(xn2, wb[6])
+    else:
+        h = K.linear_fwd(xn2, Wi_b)
+        g = K.geglu_fwd(h)
     x_out = K.linear_fwd(g, Wo2_b, resid=x_mid)
     return x_out, (x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g)
 
@@ -192,8 +200,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         it = iter(weights)
         w_an = None if i == 0 else _f32(next(it))
         Wqkv, Wo, w_mn, Wi, Wo2 = next(it), next(it), _f32(next(it)), next(it), next(it)
-        pairs = [_bf16_weight_pair(w, geo.save) for w in (Wqkv, Wo, Wi, Wo2)]
-        wb = (w_an, pairs[0][0], pairs[1][0], w_mn, pairs[2][0], pairs[3][0])
+        # forward-only and a shape of the ring kernel: the Wi GEMM stores gelu(h) * g itself (CM3P_GEGLU_FUSED=0: the two-kernel path)
+        fuse_geglu = (not geo.save) and Wi.dim() == 2 and K.gemm_geglu_supported(x.shape[0], Wi.shape[0] // 2, Wi.shape[1]) \
+            and os.environ.get("CM3P_GEGLU_FUSED", "1") != "0"
+        pairs = [_bf16_weight_pair(w, geo.save) if not (fuse_geglu and w is Wi) else (None, None) for w in (Wqkv, Wo, Wi, Wo2)]
+        wb = (w_an, pairs[0][0], pairs[1][0], w_mn, pairs[2][0], pairs[3][0], _bf16_weight_cached(Wi, True) if fuse_geglu else None)
         x_out, acts = _layer_forward(geo, i, x, wb, geo.save)
         if geo.save:
             # gradient checkpointing (ref: supports_gradient_checkpointing, TF GradientCheckpointingLayer): keep only the
@@ -221,7 +232,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             acts = ctx.saved
         x, xn, mean_a, rstd_a, qkv, o, lse, x_mid, xn2, mean_m, rstd_m, h, g = acts
         del acts
-        w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb
+        w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb[:6]
         Wqkv_t, Wo_t, Wi_t, Wo2_t = ctx.wt
         ctx.saved = ctx.wb = ctx.wt = None  # release activations as we go
         # ---- MLP branch: x_out = x_mid + g Wo2^T

@@ -64,7 +64,7 @@ def check_gemm8p(isa: str):
     registers in every accumulating MFMA."""
     no_scratch(isa, "gemm8p.hip")
     bodies = kernel_bodies(isa, "gemm8p_kernel")
-    _need(len(bodies) >= 34, f"gemm8p.hip: {len(bodies)} kernel instances found")
+    _need(len(bodies) >= 36, f"gemm8p.hip: {len(bodies)} kernel instances found")
     for sym, body in bodies.items():
         m = re.search(r"gemm8p_kernelILb[01]ELb[01]ELi\d+ELb([01])EEEv", sym)
         _need(m, f"{sym}: template arguments not recognised")

@@ -351,6 +351,30 @@ def geglu_fwd(h: Tensor) -> Tensor:
     return g
 
 
+def gemm_geglu_supported(T: int, I: int, Kd: int) -> bool:
+    """cm3p_gemm_geglu's shape rule (csrc/gemm.hip): the 256 x 256 ring kernel's big shapes."""
+    return Kd % 64 == 0 and I % 32 == 0 and T % 8 == 0 and (-(-T // 256)) * (-(-2 * I // 256)) >= 200 \
+        and not os.environ.get("CM3P_GEMM_IMPL", "").startswith("2")
+
+
+def geglu_interleave_index(I: int, device) -> Tensor:
+    """Row order of the interleaved Wi copy cm3p_gemm_geglu reads: row 64 q + r <- Wi row 32 q + r (r < 32) or I + 32 q + r - 32."""
+    n = torch.arange(2 * I, device=device)
+    r = n % 64
+    j = (n // 64) * 32 + r % 32
+    return torch.where(r < 32, j, I + j)
+
+
+def gemm_geglu(x: Tensor, w_interleaved: Tensor) -> Tensor:
+    """x [T,K] bf16, interleaved Wi [2I,K] bf16 -> gelu_erf(x Wi[:I]^T) * (x Wi[I:]^T) as bf16 [T,I] in one kernel (forward-only)."""
+    T, Kd = x.shape
+    I = w_interleaved.shape[0] // 2
+    a = _empty((T, I), torch.bfloat16, x)
+    call("cm3p_gemm_geglu", ptr(x), ptr(w_interleaved), ptr(a), T, I, Kd, stream(),
+         tag=f"gemm8p_kernel<true, true, 6, {'true' if _g8p_rebal(Kd, Kd) else 'false'}>", work=2.0 * T * 2 * I * Kd)
+    return a
+
+
 def geglu_bwd(dg: Tensor, h: Tensor) -> Tensor:
     dh = torch.empty_like(h)
     call("cm3p_geglu_bwd", ptr(dg), ptr(h), ptr(dh), h.shape[0], h.shape[1] // 2, stream(), work=10.0 * h.shape[0] * (h.shape[1] // 2))

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 11
+#define CM3P_ABI_VERSION 12
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -204,6 +204,16 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
  * h: [T, 2I] bf16, g: [T, I] bf16; I % 8 == 0.  Backward: dh from dg and h.
  */
 int cm3p_geglu_fwd(const void* h, void* g, int64_t T, int I, void* stream);
+
+/* The Wi projection and GeGLU in one kernel, for forward-only calls (evaluation, embedding extraction: nothing keeps h and g for a
+ * backward pass; replaces nn.Linear Wi + act * gate of ModernBertMLP.forward, TF:...modeling_modernbert.py:89-91, in that mode):
+ *   a[t, j] = gelu_erf(bf16(x[t] . Wi[j])) * bf16(x[t] . Wi[I + j]),  j < I      - the values cm3p_gemm_bf16 + cm3p_geglu_fwd give, bit for bit.
+ * x: [T, K] bf16; a: [T, I] bf16; w_interleaved: [2I, K] bf16 = Wi with its rows reordered so that every 64 consecutive rows are
+ * 32 rows of the first half followed by the 32 matching rows of the second half: row 64 q + r is Wi[32 q + r] for r < 32 and
+ * Wi[I + 32 q + r - 32] for r >= 32 (cm3p_amd/encoder.py makes the copy once per weight version).
+ * Shapes of the 256 x 256 ring kernel only: K % 64 == 0, I % 32 == 0, T % 8 == 0, ceil(T / 256) * ceil(2I / 256) >= 200;
+ * anything else is CM3P_ERR_INVALID and the caller keeps the two-kernel path. */
+int cm3p_gemm_geglu(const void* x, const void* w_interleaved, void* a, int64_t T, int64_t I, int64_t K, void* stream);
 int cm3p_geglu_bwd(const void* dg, const void* h, void* dh, int64_t T, int I, void* stream);
 /* y = gelu_erf(x) elementwise on bf16, and dx = dy * gelu'(x)  (nn.functional.gelu at ref:cm3p/modeling_cm3p.py:478,501-502). */
 int cm3p_gelu_fwd(const void* x, void* y, int64_t n, void* stream);

@@ -667,3 +667,19 @@ def test_dgrad_through_transposed_weight_equals_strided_dgrad(K, T, N, K_):
     assert torch.equal(a, b)
     ref = dy[:256].float() @ w.float()
     assert (b[:256].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("T,I,Kd", [(32 * 4096, 1152, 768), (8 * 4096 + 8, 1152, 768), (51200, 512, 256), (52000, 96, 192)])
+def test_wi_gemm_with_geglu_in_its_store_phase_equals_the_two_kernels(K, T, I, Kd):
+    """cm3p_gemm_geglu (forward-only calls): gelu_erf(h) * g computed on the staged bf16 rows of the Wi GEMM, with the weight rows
+    interleaved so that a wave holds the h and the g of the same columns.  Same roundings in the same places as cm3p_gemm_bf16
+    followed by cm3p_geglu_fwd: bit-identical - full tiles, a ragged last row tile, the metadata tower's width, and a width whose
+    last column tile is three quarters empty (2I = 192) with an odd number of k-tiles."""
+    assert K.gemm_geglu_supported(T, I, Kd)
+    g = torch.Generator().manual_seed(T % 1000 + I)
+    x = _bf(torch.randn(T, Kd, generator=g)).to(DEV)
+    w = _bf(torch.randn(2 * I, Kd, generator=g) * 0.05).to(DEV)
+    want = K.geglu_fwd(K.linear_fwd(x, w))
+    got = K.gemm_geglu(x, w.index_select(0, K.geglu_interleave_index(I, w.device)).contiguous())
+    assert torch.equal(got, want)
+

@@ -159,6 +159,30 @@ def test_metadata_tower_on_its_own_stream_gives_the_same_step(monkeypatch):
         assert torch.equal(res["0"][1][k], res["1"][1][k]), k
 
 
+def test_forward_only_calls_fuse_geglu_into_the_wi_gemm_without_changing_a_bit(monkeypatch):
+    """Default config, 8 x 4096 beatmap tokens under no_grad: the beatmap tower's Wi GEMMs take the fused kernel
+    (encoder._EncoderLayerFn.forward, kernels.gemm_geglu); CM3P_GEGLU_FUSED=0 keeps GEMM + geglu_fwd.  Same embeddings to the bit;
+    a training step is unaffected (it needs h and g)."""
+    from cm3p_amd import CM3PConfig, CM3PModel, _lib
+    from cm3p_amd.synthetic import synthetic_batch
+
+    cfg = CM3PConfig(beatmap_config=dict(cls_embed=False, num_hidden_layers=4), metadata_config=dict(cls_embed=False, num_hidden_layers=2))
+    torch.manual_seed(0)
+    model = CM3PModel(cfg).to(DEV).eval()
+    b = {k: v.to(DEV) for k, v in synthetic_batch(cfg, 8, 4096, 256, seed=3).items()}
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CM3P_GEGLU_FUSED", mode)
+        with torch.no_grad():
+            _lib.profile_begin()
+            o = model(input_ids=b["input_ids"], attention_mask=b.get("attention_mask"), return_loss=False)
+            tags = _lib.profile_end()
+        outs[mode] = o.beatmap_embeds.clone()
+        assert any("gemm8p_kernel<true, true, 6" in t for t in tags) == (mode == "1"), sorted(tags)
+        assert any(t.startswith("cm3p_geglu_fwd") for t in tags) == (mode == "0"), sorted(tags)
+    assert torch.equal(outs["0"], outs["1"])
+
+
 def test_forward_only_calls_reuse_bf16_weights_until_the_weight_changes():
     """No-grad calls keep the bf16 copies of the master weights (encoder._bf16_weight_cached) instead of re-casting all of them
     per call; an in-place update (what an optimizer step or load_state_dict does) or a swapped `.data` must be seen at once."""
