@@ -30,6 +30,8 @@ SIGNATURES = {
     "cm3p_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "cm3p_embed_ln_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _L, _P],
     "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
+    "cm3p_embed_ln_bwd_sorted_chunk": [],
+    "cm3p_embed_ln_bwd_sorted": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
     "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],

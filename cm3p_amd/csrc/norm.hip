@@ -312,6 +312,136 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const float* __restri
     }
 }
 
+// ---- the same backward without atomics: tokens visited in id order ------------------------------------------------------------------
+// `order` lists the tokens sorted by id (stable: ascending token index inside an id); `run_of[p]` numbers the runs of the sorted
+// sequence, a new run starting at every change of id AND at every multiple of kEmbChunk (so that a run never leaves its chunk).
+// One wave per chunk: it re-gathers each token's row, takes the LayerNorm backward and adds the row gradient to a register
+// accumulator, which is written to run_rows[run] whenever the run ends.  embed_run_sum_kernel then gives every vocabulary row the sum
+// of its runs in run order.  Every sum has a fixed order: the embedding gradient is reproducible bit for bit (the atomic kernel's
+// is not), and tokens that share an id - most of a beatmap - no longer serialise on one row of d_table.
+constexpr int kEmbChunk = 64;
+
+template <bool TAB_BF16, bool OVR_BF16, int NC>
+__global__ __launch_bounds__(256) void embed_ln_bwd_sorted_kernel(const float* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                                  const int64_t* __restrict__ order, const int32_t* __restrict__ run_of,
+                                                                  const void* __restrict__ table, const int32_t* __restrict__ slot,
+                                                                  const void* __restrict__ ovr, const float* __restrict__ w,
+                                                                  const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                  float* __restrict__ d_ovr, float* __restrict__ run_rows,
+                                                                  int64_t* __restrict__ run_ids, float* __restrict__ dw_partial,
+                                                                  int64_t T, int H, int64_t padding_idx, int64_t vocab) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+    RowRegs<NC> dw, acc;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dw.v[c] = acc.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t p0 = chunk * kEmbChunk, p1 = min(T, p0 + kEmbChunk);
+    int cur_run = -1;
+    int64_t cur_id = -1;
+    auto flush = [&]() {
+        if (cur_run < 0) return;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) *reinterpret_cast<f32x4*>(run_rows + (int64_t)cur_run * H + col) = acc.v[c];
+            acc.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (lane == 0) run_ids[cur_run] = cur_id;
+    };
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t t = order[p];
+        const int run = run_of[p];
+        if (run != cur_run) {
+            flush();
+            cur_run = run;
+            cur_id = ids[t];
+        }
+        RowRegs<NC> xr, gr;
+        load_embed_row<TAB_BF16, OVR_BF16, NC>(xr, ids, table, slot, ovr, t, H, lane, vocab);
+        load_row<false, NC>(gr, dy + t * H, H, lane);
+        const float mean = mean_in[t], rstd = rstd_in[t];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const f32x4 xhat = (xr.v[c] - mean) * rstd;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + col);
+                dw.v[c] += gr.v[c] * xhat;
+                const f32x4 g = gr.v[c] * wv;
+                xr.v[c] = xhat;
+                gr.v[c] = g;
+                s1 += (g.x + g.y) + (g.z + g.w);
+                const f32x4 gx = g * xhat;
+                s2 += (gx.x + gx.y) + (gx.z + gx.w);
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        const int sl = slot ? slot[t] : -1;
+        const int64_t id = ids[t];
+        // audio placeholders: the row gradient belongs to the audio embedding, not to the table; padding row / ids outside the table: none
+        const bool to_table = sl < 0 && id != padding_idx && (uint64_t)id < (uint64_t)vocab;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
+                if (sl >= 0) {
+                    if (d_ovr) *reinterpret_cast<f32x4*>(d_ovr + (int64_t)sl * H + col) = d;
+                } else if (to_table) {
+                    acc.v[c] += d;
+                }
+            }
+        }
+    }
+    flush();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) *reinterpret_cast<f32x4*>(dw_lds + wid * H + col) = dw.v[c];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+        dw_partial[(int64_t)blockIdx.x * H + col] = (dw_lds[col] + dw_lds[H + col]) + (dw_lds[2 * H + col] + dw_lds[3 * H + col]);
+    }
+}
+
+// d_table[v] = sum of the runs whose id is v, in run order (zero when there is none): one wave per vocabulary row.  The run ids
+// ascend (the tokens were sorted), so the first run of v is found by bisection over run_ids[0 .. n_runs).
+template <int NC>
+__global__ __launch_bounds__(256) void embed_run_sum_kernel(const float* __restrict__ run_rows, const int64_t* __restrict__ run_ids,
+                                                            const int32_t* __restrict__ run_of, float* __restrict__ d_table, int64_t T,
+                                                            int H, int64_t vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= vocab) return;
+    const int n_runs = run_of[T - 1] + 1;
+    int lo = 0, hi = n_runs;  // first run with id >= v
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run_ids[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    RowRegs<NC> acc;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = lo; r < n_runs && run_ids[r] == v; ++r) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) acc.v[c] += *reinterpret_cast<const f32x4*>(run_rows + (int64_t)r * H + col);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < H) *reinterpret_cast<f32x4*>(d_table + v * H + col) = acc.v[c];
+    }
+}
+
 // slot[t] = (ids[t] == audio_id) ? number of audio placeholders before t in row-major (b, s) order : -1.
 // Single-block exclusive scan (T is at most a few hundred thousand); count[0] = total placeholders.
 __global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __restrict__ ids, int64_t T, int64_t audio_id,
@@ -463,6 +593,44 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
     else CM3P_EMB_BWD(false, false);
 #undef CM3P_EMB_BWD
 #undef CM3P_EMB_BWD_NC
+    CM3P_LAUNCH_CHECK();
+    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_embed_ln_bwd_sorted_chunk(void) { return kEmbChunk; }
+
+int cm3p_embed_ln_bwd_sorted(const float* dy, const int64_t* ids, const int64_t* order, const int32_t* run_of, const void* table,
+                             int table_dtype, const int32_t* slot, const void* override_rows, int override_dtype, const float* weight,
+                             const float* mean, const float* rstd, float* d_table, float* d_override, float* run_rows, int64_t* run_ids,
+                             float* dw_partial, float* dw, int64_t T, int H, int64_t padding_idx, int64_t vocab, void* stream) {
+    CM3P_REQUIRE(dy && ids && order && run_of && table && weight && mean && rstd && d_table && run_rows && run_ids && dw_partial && dw);
+    CM3P_REQUIRE(T > 0 && H > 0 && H % 4 == 0 && H <= 2048 && vocab > 0);
+    CM3P_REQUIRE((slot == nullptr) == (override_rows == nullptr));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t chunks = (T + kEmbChunk - 1) / kEmbChunk;
+    const int grid = (int)((chunks + 3) / 4);
+    const size_t lds = (size_t)4 * H * sizeof(float);
+    const bool tb = table_dtype == CM3P_BF16, ob = override_dtype == CM3P_BF16;
+#define CM3P_EMB_SORT_NC(NC)                                                                                                       \
+    embed_ln_bwd_sorted_kernel<TB_, OB_, NC><<<grid, 256, lds, s>>>(dy, ids, order, run_of, table, slot, override_rows, weight, mean, \
+                                                                    rstd, d_override, run_rows, run_ids, dw_partial, T, H, padding_idx, vocab);
+#define CM3P_EMB_SORT(TB, OB)               \
+    do {                                    \
+        constexpr bool TB_ = TB, OB_ = OB;  \
+        CM3P_NC_SWITCH(H, CM3P_EMB_SORT_NC) \
+    } while (0)
+    if (tb && ob) CM3P_EMB_SORT(true, true);
+    else if (tb) CM3P_EMB_SORT(true, false);
+    else if (ob) CM3P_EMB_SORT(false, true);
+    else CM3P_EMB_SORT(false, false);
+#undef CM3P_EMB_SORT
+#undef CM3P_EMB_SORT_NC
+    CM3P_LAUNCH_CHECK();
+#define CM3P_EMB_SUM_NC(NC) embed_run_sum_kernel<NC><<<(int)((vocab + 3) / 4), 256, 0, s>>>(run_rows, run_ids, run_of, d_table, T, H, vocab);
+    CM3P_NC_SWITCH(H, CM3P_EMB_SUM_NC)
+#undef CM3P_EMB_SUM_NC
     CM3P_LAUNCH_CHECK();
     colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();

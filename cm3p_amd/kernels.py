@@ -68,6 +68,8 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
                  slot: Optional[Tensor] = None, override: Optional[Tensor] = None, want_table_grad: bool = True):
     T = ids.numel()
     V, H = table.shape
+    if want_table_grad and T > 0 and os.environ.get("CM3P_EMBED_BWD", "sorted") != "atomic":
+        return _embed_ln_bwd_sorted(dy, ids, table, weight, mean, rstd, padding_idx, slot, override)
     d_table = torch.zeros((V, H), dtype=torch.float32, device=table.device) if want_table_grad else None
     # zeros, not empty: in unpadded execution placeholder tokens at masked positions are dropped from the packed rows, their
     # rows are never written by the kernel, and zero is their true gradient
@@ -78,6 +80,37 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
     call("cm3p_embed_ln_bwd", ptr(dy), ptr(ids, torch.int64), ptr(table), dt(table), ptr(slot, torch.int32), ptr(override),
          dt(override) if override is not None else F32, ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(d_table), ptr(d_ovr), ptr(part), ptr(dw),
          T, H, padding_idx, V, stream())
+    return d_table, d_ovr, dw
+
+
+def _embed_ln_bwd_sorted(dy, ids, table, weight, mean, rstd, padding_idx, slot, override):
+    """The embedding backward without atomics (cm3p_embed_ln_bwd_sorted): tokens are visited in id order, every sum has a fixed
+    order (reproducible bit for bit, which the atomic kernel is not) and tokens that share an id do not serialise on one row.
+    The sort and the run numbering are a dozen small torch kernels on the ids (no host read)."""
+    T = ids.numel()
+    V, H = table.shape
+    dev = table.device
+    chunk = query("cm3p_embed_ln_bwd_sorted_chunk")
+    flat = ids.reshape(-1).to(torch.int64)
+    key = flat.clamp(-1, V)  # ids outside the table get no gradient: two keys for all of them bound the number of runs
+    sk, order = torch.sort(key, stable=True)
+    start = torch.ones(T, dtype=torch.bool, device=dev)
+    if T > 1:
+        start[1:] = sk[1:] != sk[:-1]
+    start |= (torch.arange(T, device=dev) % chunk) == 0
+    run_of = (torch.cumsum(start, 0) - 1).to(torch.int32)
+    R = min(T, V + 3 + T // chunk)
+    run_rows = _empty((R, H), torch.float32, table)
+    run_ids = torch.empty((R,), dtype=torch.int64, device=dev)
+    d_table = _empty((V, H), torch.float32, table)
+    d_ovr = torch.zeros(override.shape, dtype=torch.float32, device=dev) if override is not None else None
+    nblk = (-(-T // chunk) + 3) // 4
+    part = _empty((nblk, H), torch.float32, table)
+    dw = _empty((H,), torch.float32, table)
+    call("cm3p_embed_ln_bwd_sorted", ptr(dy), ptr(flat, torch.int64), ptr(order, torch.int64), ptr(run_of, torch.int32), ptr(table), dt(table),
+         ptr(slot, torch.int32), ptr(override), dt(override) if override is not None else F32, ptr(weight, torch.float32),
+         ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(d_table), ptr(d_ovr), ptr(run_rows), ptr(run_ids, torch.int64),
+         ptr(part), ptr(dw), T, H, padding_idx, V, stream())
     return d_table, d_ovr, dw
 
 

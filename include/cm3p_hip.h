@@ -70,6 +70,20 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
                       const float* rstd, float* d_table, float* d_override, float* dw_partial, float* dw, int64_t T, int H,
                       int64_t padding_idx, int64_t vocab, void* stream);
 
+/* The same backward without atomics (the default of the Python host): the caller sorts the tokens by id and the kernels visit them
+ * in that order, so every sum has a fixed order - the embedding gradient is reproducible bit for bit - and tokens that share an
+ * id do not serialise on one row of d_table.
+ *   order  [T] int64: token indices sorted by ids[.] ascending, STABLE (ascending token index inside an id);
+ *   run_of [T] int32: run number of sorted position p; a new run starts at p = 0, wherever ids[order[p]] != ids[order[p - 1]] and
+ *                     at every multiple of cm3p_embed_ln_bwd_sorted_chunk() (64), i.e. run_of = cumsum(start flags) - 1;
+ *   run_rows [R, H] fp32 and run_ids [R] int64: workspaces with R >= run_of[T - 1] + 1 (never more than min(T, vocab + T / 64 + 1));
+ *   dw_partial: [ceil(ceil(T / 64) / 4), H] fp32.  d_table [vocab, H] is fully written (no zeroing by the caller). */
+int cm3p_embed_ln_bwd_sorted_chunk(void);
+int cm3p_embed_ln_bwd_sorted(const float* dy, const int64_t* ids, const int64_t* order, const int32_t* run_of, const void* table,
+                             int table_dtype, const int32_t* slot, const void* override_rows, int override_dtype, const float* weight,
+                             const float* mean, const float* rstd, float* d_table, float* d_override, float* run_rows, int64_t* run_ids,
+                             float* dw_partial, float* dw, int64_t T, int H, int64_t padding_idx, int64_t vocab, void* stream);
+
 /* slot[t] = rank of token t among the tokens equal to audio_token_id, in row-major (b, s) order, else -1;
  * count[0] = how many there are.  The integer side of ref:cm3p/modeling_cm3p.py:604-605 (bit-exact). */
 int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int32_t* slot, int32_t* count, void* stream);

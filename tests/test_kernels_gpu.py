@@ -164,7 +164,9 @@ def test_layernorm_fwd_bwd(K, rows, H):
     _assert_close(dwb, wr.grad, 2e-4 * math.sqrt(rows), 1e-5, "ln dw (bf16 dy)")
 
 
-def test_embed_ln_with_audio_override(K):
+@pytest.mark.parametrize("impl", ["sorted", "atomic"])
+def test_embed_ln_with_audio_override(K, monkeypatch, impl):
+    monkeypatch.setenv("CM3P_EMBED_BWD", impl)
     g = torch.Generator().manual_seed(11)
     V, H, B, S = 50, 128, 3, 40
     audio_id = 49
@@ -198,6 +200,52 @@ def test_embed_ln_with_audio_override(K):
     assert d_table[0].abs().max().item() == 0.0  # padding row gets no gradient
     _assert_close(d_audio, ar.grad, 1e-4, 1e-5, "embed d_audio")
     _assert_close(dw, wr.grad, 1e-3, 1e-5, "embed dw")
+
+
+def test_embedding_backward_in_id_order_is_reproducible_and_matches_autograd(K, monkeypatch):
+    """The default embedding backward visits the tokens sorted by id (no atomics): 40000 tokens over a 300-row table with one id
+    taking 30 % of them (runs that span many 64-token chunks), the padding row, ids outside the table (no gradient, no fault) and
+    audio placeholders.  Against fp32 autograd on the CPU, bit-identical over repeated calls, and equal to the atomic kernel up to
+    its summation order."""
+    g = torch.Generator().manual_seed(21)
+    V, H, T = 300, 768, 40000
+    table = torch.randn(V, H, generator=g)
+    w = 1 + 0.1 * torch.randn(H, generator=g)
+    ids = torch.randint(0, V, (T,), generator=g)
+    ids[torch.rand(T, generator=g) < 0.3] = 17
+    audio_id = 299
+    ids[100:164] = audio_id
+    n_audio = int((ids == audio_id).sum())
+    audio = torch.randn(n_audio, H, generator=g)
+    bad = ids.clone()
+    bad[5], bad[6], bad[7] = -3, V, V + 1000  # what nn.Embedding would assert on: zero rows, no gradient
+    dy = torch.randn(T, H, generator=g)
+
+    # float64 autograd: row 17 sums 12000 token gradients, where a sequential fp32 sum is itself only good to ~1e-3
+    tr, ar, wr = (t.double().requires_grad_(True) for t in (table, audio, w))
+    safe = bad.clamp(0, V - 1)
+    emb = F.embedding(safe, tr, padding_idx=0).clone()
+    outside = (bad < 0) | (bad >= V)
+    emb[outside] = 0.0
+    emb[bad == audio_id] = ar
+    F.layer_norm(emb, (H,), wr, None, 1e-5).backward(dy.double())
+
+    slot, _ = K.audio_slots(bad.to(DEV), audio_id)
+    args = (bad.to(DEV), table.to(DEV), w.to(DEV))
+    _, _, mean, rstd = K.embed_ln_fwd(*args, 1e-5, slot, audio.to(DEV), want_bf16=False)
+    run = lambda: K.embed_ln_bwd(dy.to(DEV), *args, mean, rstd, 0, slot, audio.to(DEV))
+    monkeypatch.setenv("CM3P_EMBED_BWD", "sorted")
+    a = run()
+    b = run()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))  # fixed summation order
+    _assert_close(a[0], tr.grad, 2e-4, 3e-4, "d_table")
+    assert a[0][0].abs().max().item() == 0.0 and a[0][audio_id].abs().max().item() == 0.0
+    _assert_close(a[1], ar.grad, 1e-4, 1e-5, "d_audio")
+    _assert_close(a[2], wr.grad, 2e-3, 2e-3, "dw")
+    monkeypatch.setenv("CM3P_EMBED_BWD", "atomic")
+    c = run()
+    _assert_close(c[0], tr.grad, 2e-4, 5e-3, "atomic d_table")  # (12000 atomic adds in arrival order on row 17)
+    assert torch.equal(a[1], c[1])
 
 
 # ------------------------------------------------------------------------------------------------ RoPE / GeGLU / pool
