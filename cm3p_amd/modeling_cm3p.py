@@ -379,6 +379,7 @@ class CM3PMetadataTransformer(nn.Module):
         super().__init__()
         self.config = config
         self.encoder = CM3PEncoder(config)
+        self.unpad_inputs = None  # as CM3PBeatmapTransformer.unpad_inputs: run padded (B, L) batches on their valid tokens only
 
     def get_input_embeddings(self):
         return self.encoder.get_input_embeddings()
@@ -415,8 +416,12 @@ class CM3PMetadataTransformer(nn.Module):
             am2 = attention_mask.reshape(-1, attention_mask.size(-1)) if attention_mask is not None else None
         # output_attentions: the probabilities of every layer, (B[*V], nh, L, L) fp32 (a separate inspection kernel: the flash
         # kernels never materialise them; the reference switches to eager attention for such a call)
+        # unpadded execution of a padded batch (metadata rows are usually much shorter than the padded length - the 1000-variation
+        # evaluation is mostly padding): asked for explicitly or, like the reference, by attn_implementation == flash_attention_2;
+        # the encoder re-pads its output and keeps the padded path where packing does not apply
+        unpad = self.unpad_inputs if self.unpad_inputs is not None else getattr(self.config, "_attn_implementation", None) == "flash_attention_2"
         h = self.encoder(input_ids=ids2, attention_mask=am2, output_hidden_states=bool(output_hidden_states),
-                         output_attentions=bool(output_attentions))
+                         output_attentions=bool(output_attentions), unpad=bool(unpad) and not output_attentions)
         hiddens = attns = None
         if output_attentions:
             h, hiddens, attns = h
@@ -738,6 +743,7 @@ class CM3PModel(CM3PPreTrainedModel):
         if input_ids is not None:
             if self.unpad_inputs is not None or getattr(self.config, "_attn_implementation", None) == "flash_attention_2":
                 self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
+                self.metadata_model.unpad_inputs = self.beatmap_model.unpad_inputs
             beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
                                                  position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
                                                  cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, batch_size=batch_size, seq_len=seq_len,

@@ -498,6 +498,8 @@ def test_unpadded_and_padded_paths_agree_and_full_batches_stay_padded():
     with torch.no_grad():
         oa, ob = a(**_inputs(blob)), b(**_inputs(blob))
     assert _rel(ob.beatmap_embeds, oa.beatmap_embeds) <= 5e-3
+    assert b.metadata_model.unpad_inputs is True and _rel(ob.metadata_embeds, oa.metadata_embeds) <= 5e-3  # both towers
+    assert abs(ob.loss.item() - oa.loss.item()) <= 2e-3
     full = load_file(os.path.join(GOLD, "d64_cls_nopad.safetensors"))
     c = _build("d64_cls_nopad")
     c.unpad_inputs = True

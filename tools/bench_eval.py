@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--variations", type=int, default=1000)
     ap.add_argument("--var-batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--meta-valid", type=float, default=1.0,
+                    help="variations: valid length of a metadata row ~ U{1..meta_valid * L} (right-padded); below 1 the run is repeated with "
+                         "unpadded execution (model.unpad_inputs = True)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = CM3PConfig(beatmap_config=dict(cls_embed=False), metadata_config=dict(cls_embed=False))
@@ -87,6 +90,16 @@ def main():
                 return model(input_ids=b["input_ids"], attention_mask=b["attention_mask"], metadata_ids=mids, metadata_attention_mask=mmask,
                              metadata_variation_classes=classes, return_loss=True).loss
 
+        if args.meta_valid < 1.0:
+            lens = torch.randint(1, max(2, int(args.meta_valid * L)) + 1, (B, V), generator=g).to(dev)
+            mmask = (torch.arange(L, device=dev)[None, None, :] < lens[..., None]).to(torch.int64)
+            ms_pad = timed(run_full, args.iters)
+            model.unpad_inputs = True
+            ms_unp = timed(run_full, args.iters)
+            model.unpad_inputs = None
+            print(json.dumps({"path": "variations, right-padded metadata", "valid_fraction": float(mmask.float().mean()), "ms_padded_execution": ms_pad,
+                              "ms_unpadded_execution": ms_unp}))
+            mmask = torch.ones(B, V, L, dtype=torch.int64, device=dev)
         ms = timed(run_full, args.iters)
         fl_m = tower_flops_fwd(cfg.metadata_config, B * V * L, L)
         fl_b = tower_flops_fwd(cfg.beatmap_config, B * S, S)
