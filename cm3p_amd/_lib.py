@@ -176,13 +176,18 @@ _prof_only = None
 HBM_BOUND_TAGS = set()  # tags whose `work` is algorithmic bytes rather than FLOPs (filled by kernels.py)
 
 
-def profile_begin(only=None):
+_prof_every = 1
+_prof_seen = 0
+
+
+def profile_begin(only=None, every: int = 1):
     """Start timing C-ABI calls with HIP events on the current stream.  `only`: time just the calls with this tag - an event pair
     around every launch costs the stream about 2.5 us each, ~5 ms of a C2 step, so the judged region of bench.py brackets only
-    the dominant kernel's launches."""
-    global _prof, _prof_only
+    the dominant kernel's launches - and of those only every `every`-th one (the first, the every+1-th, ...)."""
+    global _prof, _prof_only, _prof_every, _prof_seen
     _prof = []
     _prof_only = None if only is None else ({only} if isinstance(only, str) else set(only))
+    _prof_every, _prof_seen = max(1, int(every)), 0
 
 
 def profile_end():
@@ -224,6 +229,12 @@ def call(name: str, *args, tag: str | None = None, work: float | None = None):
     if _prof is None or (_prof_only is not None and (tag or name) not in _prof_only):
         _launch(name, args)
         return
+    if _prof_every > 1:
+        global _prof_seen
+        _prof_seen += 1
+        if (_prof_seen - 1) % _prof_every:
+            _launch(name, args)
+            return
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
