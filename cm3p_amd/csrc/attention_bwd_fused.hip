@@ -28,6 +28,10 @@
 //             - exponentials carry the hardware clamp (v_exp_f32 ... clamp): p <= 1 also for keys under the padding mask, whose
 //               scores the row maximum does not bound, so dS stays finite and meets the zero K row as an exact zero.
 //   reduce  dq = scale * inverse_rope(sum of the key blocks' bf16 slabs, fp32, fixed order) -> the q third of dqkv.
+//           Two key blocks share a slab (r03): the main kernel runs twice, first over the even key blocks, which STORE their partial,
+//           then over the odd ones, which ADD theirs to the same slab with global_atomic_pk_add_bf16 (exactly one add per element,
+//           ordered behind the store by the launch boundary: deterministic; the memory side does the add, nothing is fetched).  Half
+//           the slabs to write and to reduce.
 //           (r03: the same sum done inside the fused kernel by the last workgroup of a (batch, head) to finish - ticket counter,
 //           agent-scope fences, bit-identical - was SLOWER, 5.40 vs 4.00 + 0.68 ms at B = 32, S = 4096: a reducing CU has four
 //           waves and gets 10 GB/s out of a loaded memory system, and its matrix cores idle meanwhile.  DESIGN.md.)
@@ -57,6 +61,7 @@ constexpr int kFPadTiles = 12;              // statistics tiles past ceil(S / 64
 
 __host__ __device__ inline int64_t fused_stat_floats(int B, int S, int nh) { return (int64_t)B * nh * ((S + 63) / 64 + kFPadTiles) * 128; }
 __host__ __device__ inline int fused_slab_rows(int S) { return ((S + 63) / 64) * 64 + 64; }
+__host__ __device__ inline int fused_slabs(int S) { return ((S + 255) / 256 + 1) / 2; }  // key blocks 2 j and 2 j + 1 share slab j
 
 __device__ __forceinline__ bf16x8 gload_frag8(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -127,7 +132,7 @@ __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_p
     const int S = sv.S;
     const int row = t * 64 + (tid >> 2), j = tid & 3;
     if (row >= S) return;
-    const int nkb = (Smax + 255) / 256, nkb_b = (S + 255) / 256;
+    const int nkb = fused_slabs(Smax), nkb_b = fused_slabs(S);  // (slabs, not key blocks: two key blocks share one)
     const int64_t slab = (int64_t)fused_slab_rows(Smax) * 64;
     const uint16_t* p = dq_part + ((int64_t)b * nh + head) * nkb * slab + (int64_t)row * 64 + 8 * j;
     float lo[8], hi[8];
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t*
 }
 
 // ---- fused ----------------------------------------------------------------------------------------------------------------------
-template <bool PRE>
+template <bool PRE, bool ADD>
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                                 const float* __restrict__ stat_ws, uint16_t* __restrict__ dq_part,
                                                                 uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
@@ -192,8 +197,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (tells the compiler that everything derived from it is wave-uniform)
     const int nkb = (Smax + 255) / 256, NT = (Smax + 63) / 64;
+    // this launch's key blocks: the even ones (they store their dQ partial) or, ADD, the odd ones (they add it to the same slab)
+    const int nblk = ADD ? nkb / 2 : (nkb + 1) / 2;
     int kblk, head, b;
-    decode_block(nkb, nh, kblk, head, b);
+    decode_block(nblk, nh, kblk, head, b);
+    kblk = 2 * kblk + (ADD ? 1 : 0);
     const int K0 = kblk * 256;
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
@@ -517,9 +525,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     using I8 = std::integral_constant<int, 8>;
     using I12 = std::integral_constant<int, 12>;
     // this key block's slab: rows = query rows, 64 * NT real rows + 64 dump rows
-    uint16_t* const slab = dq_part + (((int64_t)b * nh + head) * nkb + kblk) * ((int64_t)fused_slab_rows(Smax) * 64) + (lane >> 2) * 64 +
-                           32 * dq_db + 8 * (lane & 3);
+    uint16_t* const slab_u = dq_part + (((int64_t)b * nh + head) * fused_slabs(Smax) + (kblk >> 1)) * ((int64_t)fused_slab_rows(Smax) * 64) + 32 * dq_db;
+    uint16_t* const slab = slab_u + (lane >> 2) * 64 + 8 * (lane & 3);
     uint16_t* srow = slab;
+    // ADD: one dword per lane and instruction - lane l adds dword l & 15 of row 4 j + (l >> 4) of the block, j = 0 .. 7, i.e. four
+    // whole 64-byte row pieces per instruction (what the memory side's 64-byte atomic requests are made of)
+    const uint16_t* srow_u = slab_u;  // wave-uniform row base of the block (scalar registers)
+    uint32_t add_off = (uint32_t)((lane >> 4) * 128 + (lane & 15) * 4);
+    int zRd = kFZ + 2560 * wid + (lane >> 4) * 80 + (lane & 15) * 4;
+    asm volatile("" : "+v"(add_off), "+v"(zRd));
     // the wave's private transposition buffer: written in accumulator layout (lane = query row, 4 head dims per 8-byte store),
     // read back as 16-byte pieces of whole rows (80-byte row pitch: 16-byte aligned reads, 2-way conflicts on the writes)
     int zW = kFZ + 2560 * wid + l31 * 80 + 8 * hh, zR = kFZ + 2560 * wid + (lane >> 2) * 80 + (lane & 3) * 16;
@@ -557,25 +571,51 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
             }
             if constexpr (C == 6) {
                 asm volatile("" ::: "memory");  // (the uint2 stores above and these uint4 loads do not alias by type: keep their order)
-                zr0 = *reinterpret_cast<const uint4*>(smem + zR);
-                zr1 = *reinterpret_cast<const uint4*>(smem + zR + 16 * 80);
+                if constexpr (ADD) {
+                    zr0 = uint4{*reinterpret_cast<const uint32_t*>(smem + zRd), *reinterpret_cast<const uint32_t*>(smem + zRd + 320),
+                                *reinterpret_cast<const uint32_t*>(smem + zRd + 640), *reinterpret_cast<const uint32_t*>(smem + zRd + 960)};
+                    zr1 = uint4{*reinterpret_cast<const uint32_t*>(smem + zRd + 1280), *reinterpret_cast<const uint32_t*>(smem + zRd + 1600),
+                                *reinterpret_cast<const uint32_t*>(smem + zRd + 1920), *reinterpret_cast<const uint32_t*>(smem + zRd + 2240)};
+                } else {
+                    zr0 = *reinterpret_cast<const uint4*>(smem + zR);
+                    zr1 = *reinterpret_cast<const uint4*>(smem + zR + 16 * 80);
+                }
             }
             if constexpr (C == 17) {
                 // rows of epoch t-1's block: 64 (t-1) - 32 + 32 qb ..; blocks outside the sequence's tiles go to the dump rows
                 const int r = 64 * t - 96 + 32 * dq_qb;
                 const int rr = (r >= 0 && r < 64 * n_tiles) ? r : 64 * NT + 32 * dq_qb;
                 srow = slab + (int64_t)rr * 64;
+                srow_u = slab_u + (int64_t)rr * 64;
             }
             if constexpr (C == 9 && (CM3P_FABL & 16) == 0) {
-                *reinterpret_cast<uint4*>(srow) = zr0;
-                *reinterpret_cast<uint4*>(srow + 16 * 64) = zr1;
+                if constexpr (ADD) {
+                    const uint32_t ao = add_off;  // (copies: an asm operand inside a generic lambda does not capture by itself)
+                    const uint16_t* su = srow_u;
+                    const uint4 a0 = zr0, a1 = zr1;
+                    asm volatile("global_atomic_pk_add_bf16 %0, %1, %9\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %2, %9 offset:512\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %3, %9 offset:1024\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %4, %9 offset:1536\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %5, %9 offset:2048\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %6, %9 offset:2560\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %7, %9 offset:3072\n\t"
+                                 "global_atomic_pk_add_bf16 %0, %8, %9 offset:3584" ::"v"(ao), "v"(a0.x), "v"(a0.y), "v"(a0.z),
+                                 "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "s"(su)
+                                 : "memory");
+                } else {
+                    *reinterpret_cast<uint4*>(srow) = zr0;
+                    *reinterpret_cast<uint4*>(srow + 16 * 64) = zr1;
+                }
             }
         };
         step(I0{}, I1{}, WA{}, I4{}, WB{}, I8{}, I0{}, WB{}, I12{}, sA, dpA, sB, dpB, st + 8192, st + 128, nullptr, no_hook);
         step(I1{}, I0{}, WA{}, I4{}, WB{}, I12{}, I0{}, N1{}, N1{}, sB, dpB, sA, dpA, nullptr, nullptr, st + 8192, pre_hook);
         // Tile t+1 has landed: vmcnt retires in issue order and the only vector-memory operations issued after tile t+1's DMA are
         // tile t-1's two stores, tile t+2's five DMAs and tile t's two stores (every wave issues exactly these, unconditionally).
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        // (ADD: eight atomics per tile where the other instance has two stores - 8 + 5 + 8)
+        if constexpr (ADD) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         if constexpr ((CM3P_FABL & 1) == 0) lds_barrier();
         step(I0{}, I1{}, WB{}, I0{}, WA{}, I0{}, I1{}, WA{}, I4{}, sA, dpA, sB, dpB, nst, nst, nullptr, post_hook);
         step(I1{}, I0{}, WB{}, I0{}, WA{}, I4{}, I0{}, WA{}, I8{}, sB, dpB, sA, dpA, nullptr, nullptr, nst, no_hook);
@@ -678,7 +718,7 @@ extern "C" {
 int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh) {
     if (B <= 0 || S <= 0 || nh <= 0) return 0;
     const int64_t stats = (fused_stat_floats(B, S, nh) * 4 + 255) / 256 * 256;
-    return stats + (int64_t)B * nh * ((S + 255) / 256) * fused_slab_rows(S) * 128;
+    return stats + (int64_t)B * nh * fused_slabs(S) * fused_slab_rows(S) * 128;
 }
 
 int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* key_mask,
@@ -686,7 +726,7 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
                         const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* workspace,
                         int64_t workspace_bytes, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
-    CM3P_REQUIRE(stages >= 1 && stages <= 7);
+    CM3P_REQUIRE(stages >= 1 && stages <= 31);
     CM3P_REQUIRE(qkv && out && dout && lse && dqkv && workspace && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv) && cm3p_aligned16(workspace));
     if (cu_seqlens) CM3P_REQUIRE(total > 0 && key_mask == nullptr && pos_batch_stride == 0);
@@ -707,19 +747,33 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
                                                                           lse_mul, vl);
         if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
-    if (stages & CM3P_ATTN_BWD_FUSED_MAIN) {
+    const bool run_even = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_EVEN);
+    const bool run_odd = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_ODD);
+    if (run_even || run_odd) {
         static const bool attr = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
             return true;
         }();
         (void)attr;
-        const dim3 grid(((S + 255) / 256) * nh * B);  // 1-D: decode_block() maps it XCD-aware
+        // two launches: the even key blocks store their dQ partial, then the odd ones add theirs to the same slab (1-D grids:
+        // decode_block() maps them XCD-aware)
+        const int nkb = (S + 255) / 256;
+        const dim3 grid_even(((nkb + 1) / 2) * nh * B), grid_odd((nkb / 2) * nh * B);
 #define CM3P_FUSED_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, stat_ws, dq_part, (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        if (pre) attn_bwd_fused_kernel<true><<<grid, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
-        else attn_bwd_fused_kernel<false><<<grid, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+        if (run_even) {
+            if (pre) attn_bwd_fused_kernel<true, false><<<grid_even, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+            else attn_bwd_fused_kernel<false, false><<<grid_even, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+            if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+        }
+        if (run_odd && nkb > 1) {
+            if (pre) attn_bwd_fused_kernel<true, true><<<grid_odd, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+            else attn_bwd_fused_kernel<false, true><<<grid_odd, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+            if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+        }
 #undef CM3P_FUSED_ARGS
-        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
     }
     if (stages & CM3P_ATTN_BWD_FUSED_REDUCE) {
         attn_bwd_dq_reduce_kernel<<<dim3(NT, nh, B), 256, 0, s>>>(dq_part, (uint16_t*)dqkv, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);

@@ -110,8 +110,13 @@ def check_attention_bwd(isa: str):
 
 # ------------------------------------------------------------------------------------------------ attention_bwd_fused.hip
 def check_attention_bwd_fused(isa: str):
+    """The six-tile ring of attention_bwd_fused.hip.  Per tile and wave: five LDS-DMA instructions, then either two 16-byte stores
+    (the instances that store their dQ partial: counted wait vmcnt(9) = 2 + 5 + 2) or eight packed-bf16 atomic adds (the ADD
+    instances, which add theirs to a slab another launch stored: vmcnt(21) = 8 + 5 + 8); nothing else touches vector memory, no
+    accumulator copies, no scratch."""
     no_scratch(isa, "attention_bwd_fused.hip")
-    for variant in ("ILb1E", "ILb0E"):
+    for variant in ("ILb1ELb0E", "ILb0ELb0E", "ILb1ELb1E", "ILb0ELb1E"):
+        add = variant.endswith("ELb1E")
         bodies = kernel_bodies(isa, "attn_bwd_fused_kernel" + variant)
         _need(len(bodies) == 1, f"attn_bwd_fused_kernel{variant}: {len(bodies)} instances")
         sym, body = next(iter(bodies.items()))
@@ -120,13 +125,15 @@ def check_attention_bwd_fused(isa: str):
         ring = ring[-1]
         _need("v_accvgpr_write" not in ring and "v_accvgpr_read" not in ring and "scratch_" not in ring, f"{sym}: accumulator copies / scratch in the ring")
         _need(ring.count("global_load_lds_dwordx4") == 24 and ring.count("global_load_lds_dword ") == 6, f"{sym}: LDS-DMA count per ring changed")
-        _need(len(re.findall(r"\bglobal_store_dwordx4\b", ring)) == 12 and len(re.findall(r"\bglobal_(load|store)_", ring)) == 42,
-              f"{sym}: vector-memory instruction count per ring changed")
+        stores, atomics = len(re.findall(r"\bglobal_store_dwordx4\b", ring)), len(re.findall(r"\bglobal_atomic_pk_add_bf16\b", ring))
+        _need((stores, atomics) == ((0, 48) if add else (12, 0)) and len(re.findall(r"\bglobal_(load|store|atomic)_", ring)) == 30 + stores + atomics,
+              f"{sym}: vector-memory instruction count per ring changed ({stores} stores, {atomics} atomics)")
         _need(not re.search(r"\bbuffer_|\bflat_", ring), f"{sym}: buffer / flat instruction in the ring")
         _need(ring.count("s_barrier") == 6, f"{sym}: barriers per ring")
-        _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == ["9"] * 6 and "vmcnt(0)" not in ring, f"{sym}: the ring's waits are not six vmcnt(9)")
+        n = "21" if add else "9"
+        _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == [n] * 6 and "vmcnt(0)" not in ring, f"{sym}: the ring's waits are not six vmcnt({n})")
         for m in re.finditer(r"s_barrier", ring):
-            _need("vmcnt(9)" in ring[max(0, m.start() - 400):m.start()], f"{sym}: a barrier without its counted wait")
+            _need(f"vmcnt({n})" in ring[max(0, m.start() - 400):m.start()], f"{sym}: a barrier without its counted wait")
         _need(re.search(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\]", ring), f"{sym}: dQ MFMA form")
         _need(ring.count("v_exp_f32") == 384 and len(re.findall(r"v_exp_f32_e64 v\d+, v\d+ clamp", ring)) == 384, f"{sym}: exponentials / clamp")
 

@@ -271,6 +271,7 @@ def _attn_tag(fmt: str, window: int, prescaled: bool, varlen: bool = False) -> s
 
 
 ATTN_BWD_FUSED_PREP, ATTN_BWD_FUSED_MAIN, ATTN_BWD_FUSED_REDUCE = 1, 2, 4  # stages of cm3p_attn_bwd_fused
+ATTN_BWD_FUSED_MAIN_EVEN, ATTN_BWD_FUSED_MAIN_ODD = 8, 16  # the two launches of _MAIN (even key blocks store, odd ones add)
 _fused_ws: dict = {}  # (device index, stream) -> byte tensor: the fused backward's workspace, grown on demand, shared by all layers
 
 
@@ -278,7 +279,7 @@ _other_caches: list = []  # dicts other modules keep device memory in (encoder.p
 
 
 def release_workspaces() -> None:
-    """Drop the cached workspaces of the fused attention backward (3.3 GB at C2, 6.5 GB at C4 per device and stream) and the bf16
+    """Drop the cached workspaces of the fused attention backward (1.65 GB at C2, 3.3 GB at C4 per device and stream) and the bf16
     weight copies kept for forward-only calls: call it between jobs of different sequence lengths if the memory matters; the next
     call allocates what it needs."""
     _fused_ws.clear()
@@ -303,12 +304,16 @@ def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, r
     varlen = cu is not None
     rows = total if varlen else B * S
     fl = 2.0 * B * nh * S * S * 64  # one S x S x 64 product per (batch, head); SURVEY.md 8(d) credits four to the backward
+    nkb = -(-S // 256)  # 256-key blocks: the even ones are one launch, the odd ones the next
     slabs = float(need)
     for stage, name, work in (
         (ATTN_BWD_FUSED_PREP, "attn_bwd_prep_kernel", 2.0 * rows * nh * 64 * 2 + 12.0 * rows * nh),
-        (ATTN_BWD_FUSED_MAIN, "attn_bwd_fused_kernel<%s>", 4.0 * fl),
+        (ATTN_BWD_FUSED_MAIN_EVEN, "attn_bwd_fused_kernel<%s, false>", 4.0 * fl * (-(-nkb // 2)) / nkb),
+        (ATTN_BWD_FUSED_MAIN_ODD, "attn_bwd_fused_kernel<%s, true>", 4.0 * fl * (nkb // 2) / nkb),
         (ATTN_BWD_FUSED_REDUCE, "attn_bwd_dq_reduce_kernel", slabs + rows * nh * 64 * 2.0),
     ):
+        if stage == ATTN_BWD_FUSED_MAIN_ODD and nkb < 2:
+            continue  # (a single key block: nothing for the second launch)
         call("cm3p_attn_bwd_fused", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(dqkv), ptr(key_mask, torch.uint8),
              ptr(cu, torch.int32), B, S, total if varlen else 0, nh, scale, ptr(cos, torch.float32), ptr(sin, torch.float32),
              S if (per_batch and not varlen) else 0, stage, int(prescaled), ptr(ws), ws.numel(), stream(),

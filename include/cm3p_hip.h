@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 12
+#define CM3P_ABI_VERSION 13
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -200,13 +200,17 @@ int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
  * Unpadded batches: cu_seqlens [B + 1], S = max_seqlen, total rows, key_mask NULL, pos_batch_stride 0, lse [nh, total], rotary
  * tables per token (as cm3p_attn_bwd_varlen).
  * stages: CM3P_ATTN_BWD_FUSED_PREP (delta and the per-tile score offsets -> workspace), _MAIN (dk and dv thirds of dqkv; one bf16
- * partial dq per 256-key block -> workspace), _REDUCE (the dq third of dqkv from the partials, summed in fp32 in a fixed order:
+ * partial dq per PAIR of 256-key blocks -> workspace: two launches, see _MAIN_EVEN / _MAIN_ODD), _REDUCE (the dq third of dqkv from
+ * the partials, summed in fp32 in a fixed order:
  * deterministic); a caller issues all three in this order on one stream (7), or one by one to time them.
  * workspace: caller-owned device memory of at least cm3p_attn_bwd_fused_workspace_bytes(B, S, nh) bytes, 16-byte aligned;
  * contents are scratch (nothing is carried between calls). */
 #define CM3P_ATTN_BWD_FUSED_PREP 1
-#define CM3P_ATTN_BWD_FUSED_MAIN 2
+#define CM3P_ATTN_BWD_FUSED_MAIN 2      /* = _MAIN_EVEN then _MAIN_ODD */
 #define CM3P_ATTN_BWD_FUSED_REDUCE 4
+#define CM3P_ATTN_BWD_FUSED_MAIN_EVEN 8 /* the main kernel over key blocks 0, 2, 4 ...: each STORES its bf16 dq partial to slab kblk / 2 */
+#define CM3P_ATTN_BWD_FUSED_MAIN_ODD 16 /* ... over key blocks 1, 3, 5 ...: each ADDS its partial to the same slab (one packed-bf16 atomic
+                                           add per element, after the store by stream order: deterministic); must follow _MAIN_EVEN */
 int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh);
 int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* key_mask,
                         const int* cu_seqlens, int B, int S, int64_t total, int nh, float scale, const float* cos_tab,

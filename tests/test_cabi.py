@@ -58,7 +58,7 @@ def test_host_only_queries(lib_path):
     assert _lib.query("cm3p_pool_chunks", 4096) == 32
     assert 1 <= _lib.query("cm3p_layernorm_bwd_blocks", 131072) <= 2048
     # 64-bit size query: the C2 workspace of the fused attention backward is past 2^31 bytes
-    assert _lib.query("cm3p_attn_bwd_fused_workspace_bytes", 32, 4096, 12) == 32 * 12 * (76 * 512 + 16 * 4160 * 128)
+    assert _lib.query("cm3p_attn_bwd_fused_workspace_bytes", 32, 4096, 12) == 32 * 12 * (76 * 512 + 8 * 4160 * 128)  # (two 256-key blocks share a slab since ABI 13)
 
 
 def test_cpu_tensors_are_refused(lib_path):
@@ -91,7 +91,7 @@ def test_fused_attention_backward_rejects_bad_arguments_without_a_gpu(lib_path):
 
     lib = _lib.load()
     need = lib.cm3p_attn_bwd_fused_workspace_bytes(2, 512, 4)
-    assert need == 2 * 4 * ((8 + 12) * 512 + 2 * (512 + 64) * 128)
+    assert need == 2 * 4 * ((8 + 12) * 512 + 1 * (512 + 64) * 128)  # (S = 512: two key blocks, one shared slab)
     fake = 4096  # an aligned, never dereferenced address: every call below must fail validation first
     args = dict(qkv=fake, out=fake, dout=fake, lse=fake, dqkv=fake, key_mask=None, cu=None, B=2, S=512, total=0, nh=4, scale=0.125, cos=None, sin=None,
                 pbs=0, stages=7, pre=1, ws=fake, ws_bytes=need, stream=None)
@@ -104,7 +104,7 @@ def test_fused_attention_backward_rejects_bad_arguments_without_a_gpu(lib_path):
     assert call(qkv=None) == -1
     assert call(ws=None) == -1
     assert call(ws_bytes=need - 1) == -1
-    assert call(stages=0) == -1 and call(stages=8) == -1
+    assert call(stages=0) == -1 and call(stages=32) == -1
     assert call(cos=fake, sin=None) == -1
     assert call(cu=fake, total=0) == -1  # packed rows need their total
     assert call(qkv=fake + 2) == -1  # 16-byte alignment
