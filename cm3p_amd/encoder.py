@@ -98,10 +98,21 @@ _eval_weights: dict = {}  # id(parameter) -> (weakref to it, its _version, its d
 K._other_caches.append(_eval_weights)  # (kernels.release_workspaces() empties it)
 
 
+def invalidate_weight_cache() -> None:
+    """Drop the bf16 weight copies kept across forward-only calls.  Called by every forward that will be followed by a backward (a
+    training step means an optimizer is about to rewrite the weights, whatever it is and however it writes them) and by
+    `module.train()` / `module.eval()` mode flips of an encoder; call it by hand after writing weights in a way that leaves no trace
+    on the parameter (`p.data.copy_(...)`, an EMA swap through `.data`, a kernel that takes `p.data_ptr()`) between two
+    forward-only calls."""
+    _eval_weights.clear()
+
+
 def _bf16_weight_cached(w: Tensor, geglu_rows: bool = False) -> Tensor:
     """Forward-only calls (no backward will follow: evaluation, embedding extraction) reuse the bf16 copy of a master weight for
-    as long as the weight is the same object with the same version counter and storage - every in-place update (optimizer step,
-    load_state_dict) bumps the counter, `p.data = ...` changes the address.  A training step re-casts every weight once anyway.
+    as long as the weight is the same object with the same version counter and storage - every in-place torch op (torch optimizers,
+    load_state_dict) bumps the counter, `p.data = ...` changes the address, and writers that go through raw addresses bump it by hand
+    (cm3p_amd.Muon.step does).  Writes through `p.data` bump nothing: see invalidate_weight_cache().  A training step re-casts every
+    weight once anyway and empties the cache.
     geglu_rows: the copy of a Wi weight with its rows in the order cm3p_gemm_geglu reads (kernels.geglu_interleave_index)."""
     key = (id(w), geglu_rows)
     hit = _eval_weights.get(key)
@@ -383,6 +394,11 @@ class CM3PEncoder(nn.Module):
             layer.mlp.Wi._cm3p_init = (std_in, cutoff)
             layer.mlp.Wo._cm3p_init = (std_out, cutoff)
 
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            invalidate_weight_cache()  # HF Trainer flips the mode around every evaluation: copies never cross a train/eval boundary
+        return super().train(mode)
+
     def get_input_embeddings(self):
         return self.embeddings.tok_embeddings
 
@@ -510,6 +526,8 @@ class CM3PEncoder(nn.Module):
         weights = self._stack_weights()
         geo.save = torch.is_grad_enabled() and (x0.requires_grad or self.final_norm.weight.requires_grad
                                                 or any(w.requires_grad for ws in weights for w in ws))
+        if geo.save and _eval_weights:
+            invalidate_weight_cache()  # a backward will follow, so an optimizer will: no copy made before this step may outlive it
         geo.handoff = None
         geo.attn_out = [] if output_attentions else None
         # output_hidden_states: the stack's input and every layer's output (TF:...modeling_modernbert.py:457-470), detached

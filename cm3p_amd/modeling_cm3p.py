@@ -732,6 +732,10 @@ class CM3PModel(CM3PPreTrainedModel):
         # 8192 tokens at C2) runs on a second stream BESIDE the beatmap tower instead of after it; autograd runs each node's
         # backward on its forward stream and orders the gradients across streams, so the backward overlaps the same way.
         # Not with gathered negatives / more than one rank (DDP's bucket hooks take the stream of the last gradient of a bucket).
+        # (both towers learn the unpadding rule before either is launched: with the towers overlapped the metadata tower goes first)
+        if self.unpad_inputs is not None or getattr(self.config, "_attn_implementation", None) == "flash_attention_2":
+            self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
+            self.metadata_model.unpad_inputs = self.beatmap_model.unpad_inputs
         side = None
         if self._overlap_towers(input_ids, metadata_ids):
             main = torch.cuda.current_stream(metadata_ids.device)
@@ -741,14 +745,16 @@ class CM3PModel(CM3PPreTrainedModel):
                 metadata_outputs, metadata_embeds = run_metadata()
 
         if input_ids is not None:
-            if self.unpad_inputs is not None or getattr(self.config, "_attn_implementation", None) == "flash_attention_2":
-                self.beatmap_model.unpad_inputs = True if self.unpad_inputs is None else bool(self.unpad_inputs)
-                self.metadata_model.unpad_inputs = self.beatmap_model.unpad_inputs
-            beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
-                                                 position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
-                                                 cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, batch_size=batch_size, seq_len=seq_len,
-                                                 output_attentions=output_attentions, output_hidden_states=output_hidden_states)
-            beatmap_embeds = _L2NormFn.apply(_ProjectFn.apply(beatmap_outputs.pooler_output, self.beatmap_projection.weight))
+            try:
+                beatmap_outputs = self.beatmap_model(input_ids=input_ids, input_features=input_features, attention_mask=attention_mask,
+                                                     position_ids=position_ids, inputs_embeds=inputs_embeds, indices=indices,
+                                                     cu_seqlens=cu_seqlens, max_seqlen=max_seqlen, batch_size=batch_size, seq_len=seq_len,
+                                                     output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+                beatmap_embeds = _L2NormFn.apply(_ProjectFn.apply(beatmap_outputs.pooler_output, self.beatmap_projection.weight))
+            except BaseException:
+                if side is not None:  # the metadata tower is in flight on the other stream: join it before its tensors are dropped
+                    main.wait_stream(side)
+                raise
             if self.gather_negatives and metadata_ids is not None:
                 if metadata_ids.dim() == 2:
                     # start the all-gather now: it runs on the process group's side stream under the whole metadata tower and is

@@ -174,6 +174,14 @@ class Muon(torch.optim.Optimizer):
             # launches below take raw addresses (no tensor to read the device from): make the parameters' GPU current
             with torch.cuda.device(device):
                 self._step_group(gi, group, shape_groups, adamw, device, lr, momentum)
+            # The kernels wrote the parameters through raw addresses: tell autograd (and every cache keyed on a parameter's version
+            # counter - encoder._bf16_weight_cached keeps bf16 weight copies across forward-only calls) that they changed, as an
+            # in-place torch op would have.
+            for items in shape_groups.values():
+                for p, _, _ in items:
+                    _bump_version(p)
+            for p, _, _ in adamw:
+                _bump_version(p)
         return loss
 
     def _step_group(self, gi, group, shape_groups, adamw, device, lr, momentum):
@@ -252,6 +260,14 @@ class Muon(torch.optim.Optimizer):
                  len(items), max(p.numel() for p, _, _ in items), float(1 - b1), float(1 - b2), float(group["adamw_eps"]),
                  float(1 - adamw_lr * group["adamw_wd"]), float(-lr / scale), st, tag="adamw_multi",
                  work=28.0 * sum(p.numel() for p, _, _ in items))
+
+
+def _bump_version(p: torch.Tensor) -> None:
+    """What any in-place torch op does to its output's version counter; a raw-pointer writer has to do it by hand."""
+    try:
+        torch.autograd.graph.increment_version(p)
+    except AttributeError:  # older torch
+        torch._C._increment_version(p)
 
 
 __all__ = ["Muon", "newton_schulz_batched"]

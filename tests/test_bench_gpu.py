@@ -53,6 +53,25 @@ def test_bench_two_ranks_share_the_card_over_gloo():
     assert d["comm"]["gradient_bytes_per_step"] > 0
 
 
+def test_bench_starts_its_own_ranks_when_called_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's N = 1 command with another --gpus): the process
+    must start its two ranks itself as child processes, relay rank 0's single JSON line and exit with their code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CM3P_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-optimizer"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout: the launcher adds nothing of its own there
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["replicas"]["identical_on_all_ranks"] is True
+    # and a failing rank's exit code comes back through the launcher
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-optimizer"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(env, CM3P_BENCH_INJECT_FAILURE_RANK="0", CM3P_BENCH_PG_TIMEOUT_S="60"))
+    assert p.returncode != 0 and "[bench] rank 0: RuntimeError: injected failure" in p.stderr
+
+
 def _torchrun(n, extra_env, *args, port="29543"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",

@@ -214,6 +214,60 @@ def test_forward_only_calls_reuse_bf16_weights_until_the_weight_changes():
     assert torch.isfinite(out.loss)
 
 
+def test_evaluation_after_an_optimizer_step_sees_the_new_weights():
+    """eval -> training step with cm3p_amd.Muon (which writes the weights through raw addresses: no torch op touches them) -> eval:
+    the second evaluation must run on the updated weights, i.e. equal a run whose cache was emptied by hand.  The same for an
+    optimizer step with no training forward of its own in between (gradients left over from an earlier backward) and for a torch
+    optimizer."""
+    from cm3p_amd import encoder as E
+    from cm3p_amd.muon import Muon
+
+    name = "d64_mean_pad"
+    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
+    model = _build(name)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    adamw = [p for n, p in named if "embed" in n.lower() or p.ndim <= 1]
+    ids = {id(p) for p in adamw}
+    opt = Muon(muon_params=[p for _, p in named if id(p) not in ids], lr=0.05, adamw_params=adamw, adamw_lr=1e-2)
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            return model(**_inputs(blob)).logits_per_metadata.clone()
+
+    def evaluate_uncached():
+        E.invalidate_weight_cache()
+        return evaluate()
+
+    first = evaluate()
+    assert len(E._eval_weights) > 0
+    model.train()
+    model(**_inputs(blob)).loss.backward()
+    opt.step()
+    second = evaluate()
+    assert torch.equal(second, evaluate_uncached()) and not torch.equal(second, first)
+    # a step between two evaluations with NO training forward in between (the gradients are still there): only the version
+    # counters that Muon.step bumps say that the weights moved
+    assert len(E._eval_weights) > 0
+    v0 = model.beatmap_model.encoder.layers[1].attn.Wqkv.weight._version
+    opt.step()
+    assert model.beatmap_model.encoder.layers[1].attn.Wqkv.weight._version > v0
+    third = evaluate()
+    assert torch.equal(third, evaluate_uncached()) and not torch.equal(third, second)
+    # a torch optimizer
+    sgd = torch.optim.SGD(model.parameters(), lr=0.5)
+    sgd.step()
+    fourth = evaluate()
+    assert torch.equal(fourth, evaluate_uncached()) and not torch.equal(fourth, third)
+    # a write through `.data` leaves no trace on the parameter: the documented way is invalidate_weight_cache(), and a mode flip
+    # (what HF Trainer does around every evaluation) empties the cache as well
+    w = model.beatmap_model.encoder.layers[0].mlp.Wo.weight
+    w.data.mul_(1.25)
+    model.train()
+    fifth = evaluate()
+    assert torch.equal(fifth, evaluate_uncached()) and not torch.equal(fifth, fourth)
+
+
 def test_inputs_on_cpu_are_refused():
     from cm3p_amd import CM3PConfig, CM3PModel
 
