@@ -249,7 +249,20 @@ def launch_ranks(n: int) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool's driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    # rank 0's JSON line is the only thing that belongs on stdout; whatever else the ranks or their libraries print there (gloo's
+    # "[Gloo] Rank 0 is connected ..." banner goes to stdout) is passed on to stderr, so that the caller can parse stdout as it does at N = 1
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        at = line.find('{"metric"')
+        if at >= 0:
+            if at:
+                sys.stderr.write(line[:at] + "\n")
+            sys.stdout.write(line[at:])
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+    return proc.wait()
 
 
 def main():
