@@ -14,13 +14,13 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
-_RETURNS_INT64 = {"cm3p_attn_bwd_fused_workspace_bytes"}  # size queries that do not fit an int
+_RETURNS_INT64 = {"cm3p_attn_bwd_fused_workspace_bytes", "cm3p_token_order_workspace_ints"}  # size queries that do not fit an int
 
 # name -> argtypes, mirrors include/cm3p_hip.h one to one
 SIGNATURES = {
@@ -32,6 +32,8 @@ SIGNATURES = {
     "cm3p_embed_ln_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
     "cm3p_embed_ln_bwd_sorted_chunk": [],
     "cm3p_embed_ln_bwd_sorted": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _L, _P],
+    "cm3p_token_order_workspace_ints": [_L, _L],
+    "cm3p_token_order": [_P, _L, _L, _P, _P, _P, _P],
     "cm3p_audio_slots": [_P, _L, _L, _P, _P, _P],
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],

@@ -143,8 +143,8 @@ __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_p
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int kb = min(kb0 + u, nkb_b - 1);  // (past the last block: a repeated load, not summed)
-            a[u] = *reinterpret_cast<const uint4*>(p + kb * slab);
-            c[u] = *reinterpret_cast<const uint4*>(p + kb * slab + 32);
+            a[u] = gload16<(CM3P_NT & 8) != 0>(p + kb * slab);
+            c[u] = gload16<(CM3P_NT & 8) != 0>(p + kb * slab + 32);
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -171,10 +171,10 @@ __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_p
         }
     }
     uint16_t* drow = dqkv + (sv.row0 + row) * ((int64_t)3 * nh * 64) + head * 64 + 8 * j;
-    *reinterpret_cast<uint4*>(drow) = uint4{pack_bf16x2(lo[0] * scale, lo[1] * scale), pack_bf16x2(lo[2] * scale, lo[3] * scale),
-                                            pack_bf16x2(lo[4] * scale, lo[5] * scale), pack_bf16x2(lo[6] * scale, lo[7] * scale)};
-    *reinterpret_cast<uint4*>(drow + 32) = uint4{pack_bf16x2(hi[0] * scale, hi[1] * scale), pack_bf16x2(hi[2] * scale, hi[3] * scale),
-                                                 pack_bf16x2(hi[4] * scale, hi[5] * scale), pack_bf16x2(hi[6] * scale, hi[7] * scale)};
+    gstore16<(CM3P_NT & 8) != 0>(drow, uint4{pack_bf16x2(lo[0] * scale, lo[1] * scale), pack_bf16x2(lo[2] * scale, lo[3] * scale),
+                                             pack_bf16x2(lo[4] * scale, lo[5] * scale), pack_bf16x2(lo[6] * scale, lo[7] * scale)});
+    gstore16<(CM3P_NT & 8) != 0>(drow + 32, uint4{pack_bf16x2(hi[0] * scale, hi[1] * scale), pack_bf16x2(hi[2] * scale, hi[3] * scale),
+                                                  pack_bf16x2(hi[4] * scale, hi[5] * scale), pack_bf16x2(hi[6] * scale, hi[7] * scale)});
 }
 
 // the reduction as its own launch: grid (tiles, nh, B), 256 threads
@@ -604,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
                                  "v"(a0.w), "v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w), "s"(su)
                                  : "memory");
                 } else {
-                    *reinterpret_cast<uint4*>(srow) = zr0;
-                    *reinterpret_cast<uint4*>(srow + 16 * 64) = zr1;
+                    gstore16<(CM3P_NT & 2) != 0>(srow, zr0);
+                    gstore16<(CM3P_NT & 2) != 0>(srow + 16 * 64, zr1);
                 }
             }
         };

@@ -171,7 +171,7 @@ __device__ __forceinline__ void store_rows32(char* buf, const f32x16& b0, const 
     for (int i = 0; i < 4; ++i) {
         const int row = (lane >> 3) + 8 * i;
         const uint4 v = *reinterpret_cast<const uint4*>(buf + row * 144 + (lane & 7) * 16);
-        if (row < nrows_valid) *reinterpret_cast<uint4*>(dst_row0 + row * ld_elems + (lane & 7) * 8) = v;
+        if (row < nrows_valid) gstore16<(CM3P_NT & 4) != 0>(dst_row0 + row * ld_elems + (lane & 7) * 8, v);
     }
     asm volatile("" ::: "memory");
 }

@@ -25,6 +25,51 @@ struct BatchArgs {
     float alpha = 1.f, beta = 0.f;
 };
 
+// Cache policy of write-once / read-once global traffic.  A plain store leaves its line in the XCD's 4 MiB L2, where it pushes out
+// what the workgroups of that XCD re-read (GEMM operand panels, the K / V or Q / dO tiles of an attention head); a non-temporal
+// store ("nt") asks for the line to be the first to go.  Same bytes, same results; which sites pay was measured (DESIGN section 4,
+// r04 "output stores").  Bit mask so that variants can be built for an A/B (tools/ubench/nt_variants.sh):
+//   1 gemm8p bf16 epilogues   2 fused attention backward: dQ partial slabs   4 attention outputs written through store_rows32
+//   8 dQ slab reduce (slab loads and dq stores)   16 LayerNorm / GeGLU outputs   32 gemm8p fp32 epilogues
+//   64 gemm8p residual loads (read once)
+#ifndef CM3P_NT
+#define CM3P_NT 7
+#endif
+typedef __attribute__((ext_vector_type(4))) uint32_t cm3p_u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t cm3p_u32x2;
+template <bool NT>
+__device__ __forceinline__ void gstore16(void* p, cm3p_u32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, static_cast<cm3p_u32x4*>(p));
+    else *static_cast<cm3p_u32x4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void gstore16(void* p, uint4 v) { gstore16<NT>(p, cm3p_u32x4{v.x, v.y, v.z, v.w}); }
+template <bool NT>
+__device__ __forceinline__ void gstore16f(void* p, __attribute__((ext_vector_type(4))) float v) {
+    gstore16<NT>(p, __builtin_bit_cast(cm3p_u32x4, v));
+}
+template <bool NT>
+__device__ __forceinline__ void gstore8(void* p, uint2 v) {
+    if constexpr (NT) __builtin_nontemporal_store(cm3p_u32x2{v.x, v.y}, static_cast<cm3p_u32x2*>(p));
+    else *static_cast<uint2*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ uint4 gload16(const void* p) {
+    if constexpr (NT) {
+        const cm3p_u32x4 v = __builtin_nontemporal_load(static_cast<const cm3p_u32x4*>(p));
+        return uint4{v[0], v[1], v[2], v[3]};
+    } else {
+        return *static_cast<const uint4*>(p);
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float gload16f(const void* p) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    if constexpr (NT) return __builtin_nontemporal_load(static_cast<const f4*>(p));
+    else return *static_cast<const f4*>(p);
+}
+
 // Every extern "C" entry point ends with this: kernels never throw, launch errors become a return code.
 #define CM3P_LAUNCH_CHECK()                                         \
     do {                                                            \

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restri
         unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + I + c * 8), b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = gelu_erf(a[j]) * b[j];
-        *reinterpret_cast<uint4*>(g + t * I + c * 8) = pack8(y);
+        gstore16<(CM3P_NT & 16) != 0>(g + t * I + c * 8, pack8(y));
     }
 }
 
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restri
             da[j] = d[j] * b[j] * gelu_erf_grad(a[j]);
             db[j] = d[j] * gelu_erf(a[j]);
         }
-        *reinterpret_cast<uint4*>(dh + t * 2 * I + c * 8) = pack8(da);
-        *reinterpret_cast<uint4*>(dh + t * 2 * I + I + c * 8) = pack8(db);
+        gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + c * 8, pack8(da));
+        gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + I + c * 8, pack8(db));
     }
 }
 

@@ -277,6 +277,13 @@ static inline bool use_8p() {
     return !(e && e[0] == '2');
 }
 
+// CM3P_GEMM_IMPL=128: the 128 x 128 kernel (two to three workgroups per CU) for every shape - an A/B partner for shapes whose
+// epilogue dominates (tools/gemm_ab.py)
+static inline bool use_small_only() {
+    const char* e = getenv("CM3P_GEMM_IMPL");
+    return e && e[0] == '1';
+}
+
 static inline int big_gemm(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                            int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s,
                            RopeArgs rope) {
@@ -328,7 +335,7 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
     CM3P_REQUIRE(q_scale > 0.f && rope_cols % 2 == 0);
     const RopeArgs rope{cos_tab, sin_tab, S, per_batch, rope_cols, rope_cols / 2, q_scale};
     // (the 256 x 256 kernel decides per tile whether its columns are rotated: the rotated range must end on a tile boundary)
-    const bool big = (K % 64 == 0) && (rope_cols % 256 == 0) && M < (int64_t(1) << 31) && tiles_of(M, N, 256) >= 200;
+    const bool big = (K % 64 == 0) && (rope_cols % 256 == 0) && M < (int64_t(1) << 31) && tiles_of(M, N, 256) >= 200 && !use_small_only();
     int rc;
     if (big) rc = big_gemm(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, 1, 1, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
     else rc = launch<true, true>(x, Wqkv, qkv, nullptr, M, N, K, K, K, N, CM3P_EPI_BF16_ROPE, 1, K, 0, s, rope);
@@ -364,7 +371,7 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
         split_stride = M * N;
     }
     int rc;
-    const bool big = (K % 64 == 0) && (kchunk % 64 == 0) && tiles_of(M, N, 256) * split_k >= 200;
+    const bool big = (K % 64 == 0) && (kchunk % 64 == 0) && tiles_of(M, N, 256) * split_k >= 200 && !use_small_only();
     if (big) rc = big_gemm(A, B, out, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, kchunk, split_stride, s, RopeArgs{});
     else if (a_kc && b_kc) rc = launch<true, true>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     else if (a_kc) rc = launch<true, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);

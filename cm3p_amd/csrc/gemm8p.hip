@@ -35,7 +35,8 @@
                         // epilogue, 2 no epilogue at all, 4 accumulators not zeroed, 8 no counted vmcnt wait in phase 4,
                         // 16 every second workgroup of an XCD starts CM3P_G8P_DELAY x ~0.5 us late (de-phasing probe; results valid),
                         // 32 no B-lo fragment reads in phase 1 (stale registers: what moving them out of the longest phase could buy),
-                        // 64 no LDS-DMA in the k-loop (stale tiles: the cost of issuing the operand stream)
+                        // 64 no LDS-DMA in the k-loop (stale tiles: the cost of issuing the operand stream),
+                        // 128 the RoPE instance does not read its cos / sin tables (what their traffic costs)
 #endif
 #ifndef CM3P_G8P_DELAY
 #define CM3P_G8P_DELAY 10
@@ -410,8 +411,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                         }
                         const float* cr = rope.cos + prow * 32 + dc * 8;
                         const float* sr = rope.sin + prow * 32 + dc * 8;
-                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
-                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+                        f32x4 c0, c1, s0, s1;
+                        if constexpr (CM3P_G8P_ABL & 128) {
+                            asm volatile("" : "=v"(c0), "=v"(c1), "=v"(s0), "=v"(s1) : "v"(cr), "v"(sr));
+                        } else {
+                            c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+                            s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+                        }
                         const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                         const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
                         u32x4 oa, ob;
@@ -432,8 +438,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     const u32x4 x1 = *reinterpret_cast<const u32x4*>(eb + r1 * 128 + ((ch ^ (r1 & 7)) << 4));
                     G8P_LANE_XCHG_FENCE();
                     const bool col_ok = FULL || nw + ch * 8 < N;
-                    if (FULL || (col_ok && mw + i4 * 16 + r0 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r0) * ldcb + ch * 16) = x0);
-                    if (FULL || (col_ok && mw + i4 * 16 + r1 < M)) G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + r1) * ldcb + ch * 16) = x1);
+                    if (FULL || (col_ok && mw + i4 * 16 + r0 < M)) G8P_GLOBAL(gstore16<(CM3P_NT & 1) != 0>(Cb + (uint32_t)(i4 * 16 + r0) * ldcb + ch * 16, x0));
+                    if (FULL || (col_ok && mw + i4 * 16 + r1 < M)) G8P_GLOBAL(gstore16<(CM3P_NT & 1) != 0>(Cb + (uint32_t)(i4 * 16 + r1) * ldcb + ch * 16, x1));
                     if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x0), "v"(x1));
                 }
             }
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                 for (int t = 0; t < 4; ++t)
                     y[t] = pack_bf16x2(gelu_erf8p(bf16lo(xh[t])) * bf16lo(xg[t]), gelu_erf8p(bf16hi(xh[t])) * bf16hi(xg[t]));
                 if (FULL || (mw + i4 * 16 + row < M && nw + dc * 8 < N))
-                    G8P_GLOBAL(*reinterpret_cast<u32x4*>(Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16) = y);
+                    G8P_GLOBAL(gstore16<(CM3P_NT & 1) != 0>(Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16, y));
                 if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(y));
             }
         } else if constexpr (EPI == CM3P_EPI_BF16_AXPBY) {
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int row = i4 * 16 + u * 4;
-                        rnext[u] = (FULL || (col_ok && mw + row + lrow < M)) ? *reinterpret_cast<const f32x4*>(Rb + loff + (uint32_t)row * ldcb)
+                        rnext[u] = (FULL || (col_ok && mw + row + lrow < M)) ? gload16f<(CM3P_NT & 64) != 0>(Rb + loff + (uint32_t)row * ldcb)
                                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = i4 * 16 + u * 4;
-                    if (FULL || (col_ok && mw + row + lrow < M)) G8P_GLOBAL(*reinterpret_cast<f32x4*>(Cb + loff + (uint32_t)row * ldcb) = x[u]);
+                    if (FULL || (col_ok && mw + row + lrow < M)) G8P_GLOBAL(gstore16f<(CM3P_NT & 32) != 0>(Cb + loff + (uint32_t)row * ldcb, x[u]));
                     if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(x[u]));
                 }
             }

@@ -67,8 +67,8 @@ __device__ __forceinline__ void store_norm(const RowRegs<NC>& r, const float* __
         if (col < H) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(w + col);
             const f32x4 y = (r.v[c] - mean) * rstd * g;
-            if (y32) *reinterpret_cast<f32x4*>(y32 + col) = y;
-            if (y16) *reinterpret_cast<uint2*>(y16 + col) = uint2{pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+            if (y32) gstore16f<(CM3P_NT & 16) != 0>(y32 + col, y);
+            if (y16) gstore8<(CM3P_NT & 16) != 0>(y16 + col, uint2{pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)});
         }
     }
 }
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
             if (col < H) {
                 f32x4 d = (gr.v[c] - s1 - xr.v[c] * s2) * rstd;
                 if (dres) d += rr.v[c];
-                if (dx32) *reinterpret_cast<f32x4*>(dx32 + row * H + col) = d;
-                if (dx16) *reinterpret_cast<uint2*>(dx16 + row * H + col) = uint2{pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w)};
+                if (dx32) gstore16f<(CM3P_NT & 16) != 0>(dx32 + row * H + col, d);
+                if (dx16) gstore8<(CM3P_NT & 16) != 0>(dx16 + row * H + col, uint2{pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w)});
             }
         }
     }
@@ -472,6 +472,165 @@ __global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __rest
     if (threadIdx.x == 0) count[0] = carry;
 }
 
+// ---- token order for the embedding backward: a stable counting sort of the ids -----------------------------------------------
+// What cm3p_embed_ln_bwd_sorted needs from the ids alone: the tokens in ascending-id order, ties in token order (`order`), and the
+// run number of every sorted position (`run_of`: a new run where the id changes and at every multiple of kEmbChunk).  Keys are
+// clamp(id, -1, vocab) + 1 in [0, vocab + 2): ids outside the table share the two end buckets.  Token ids are small integers
+// (beatmap vocabulary 3167), so this is a counting sort in four launches, nothing read by the host:
+//   1. per block of kOrdBlock consecutive tokens, a histogram of its keys -> cnt[key][block];
+//   2. per key the exclusive prefix of cnt over the blocks and the key's total, then an exclusive scan of the totals over the keys:
+//      key start + prefix = the first sorted position of each (key, block) pair;
+//   3. each block hands its tokens their positions in token order (one wave walks the block 64 tokens at a time; within a wave
+//      the lanes that share a key rank themselves with a ballot), writing order[] and the sorted keys;
+//   4. run starts from the sorted keys and their running count (two launches over blocks of 1024 positions).
+constexpr int kOrdBlock = 1024;     // tokens per block of the histogram / scatter kernels
+constexpr int kOrdMaxKeys = 12288;  // LDS: one int per key
+
+__global__ __launch_bounds__(256) void token_hist_kernel(const int64_t* __restrict__ ids, int64_t T, int64_t vocab, int nblk,
+                                                         int32_t* __restrict__ cnt) {
+    extern __shared__ int hist[];
+    const int nkeys = (int)vocab + 2;
+    for (int k = threadIdx.x; k < nkeys; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * kOrdBlock;
+    for (int i = threadIdx.x; i < kOrdBlock; i += 256) {
+        const int64_t t = t0 + i;
+        if (t < T) {
+            const int64_t id = ids[t];
+            const int key = (int)(id < 0 ? -1 : (id > vocab ? vocab : id)) + 1;
+            atomicAdd(&hist[key], 1);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nkeys; k += 256) cnt[(int64_t)k * nblk + blockIdx.x] = hist[k];
+}
+
+// one wave per key: cnt[key][0 .. nblk) -> its exclusive prefix over the blocks (in place), key_total[key] = the key's token count
+__global__ __launch_bounds__(256) void token_key_prefix_kernel(int32_t* __restrict__ cnt, int32_t* __restrict__ key_total, int nkeys, int nblk) {
+    const int lane = threadIdx.x & 63;
+    const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (key >= nkeys) return;
+    int32_t* row = cnt + (int64_t)key * nblk;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const int c = b < nblk ? row[b] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (b < nblk) row[b] = carry + incl - c;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) key_total[key] = carry;
+}
+
+// in-place exclusive scan of n ints (n = number of keys: a few thousand) by ONE block of 1024 threads, coalesced tiles of 1024
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(int32_t* __restrict__ v, int n) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int c = i < n ? v[i] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        int off = carry_s + incl - c;
+        for (int w = 0; w < wid; ++w) off += wave_tot[w];
+        if (i < n) v[i] = off;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = off + c;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void token_scatter_kernel(const int64_t* __restrict__ ids, int64_t T, int64_t vocab, int nblk,
+                                                           const int32_t* __restrict__ first, const int32_t* __restrict__ key_start,
+                                                           int64_t* __restrict__ order, int32_t* __restrict__ sorted_key) {
+    extern __shared__ int next[];  // next free sorted position of each key, for this block's tokens
+    const int lane = threadIdx.x;
+    const int nkeys = (int)vocab + 2;
+    for (int k = lane; k < nkeys; k += 64) next[k] = key_start[k] + first[(int64_t)k * nblk + blockIdx.x];
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * kOrdBlock;
+    for (int c = 0; c < kOrdBlock; c += 64) {
+        const int64_t t = t0 + c + lane;
+        const bool live = t < T;
+        int key = -1;
+        if (live) {
+            const int64_t id = ids[t];
+            key = (int)(id < 0 ? -1 : (id > vocab ? vocab : id)) + 1;
+        }
+        // the lanes of a key, lowest token first, take consecutive positions; one round per distinct key of these 64 tokens
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int k = __shfl(key, leader, 64);
+            const unsigned long long same = __ballot(live && key == k);
+            // (a wave's LDS operations execute in order: every lane's read of next[k] precedes the leader's update; volatile keeps the
+            //  compiler from carrying a value of next[] across rounds)
+            volatile int* nk = next + k;
+            if (live && key == k) {
+                const int pos = *nk + __popcll(same & ((1ull << lane) - 1ull));
+                order[pos] = t;
+                sorted_key[pos] = k;
+            }
+            if (lane == leader) *nk += __popcll(same);
+            todo &= ~same;
+        }
+    }
+}
+
+// run_of[p] = (number of run starts at positions <= p) - 1; a run starts at p = 0, where the sorted key changes and at every multiple of
+// `chunk`.  Two launches over blocks of 1024 positions: count the starts per block, then number them behind the earlier blocks' sum.
+__device__ __forceinline__ bool run_starts(const int32_t* __restrict__ sorted_key, int64_t p, int chunk) {
+    return p == 0 || sorted_key[p] != sorted_key[p - 1] || p % chunk == 0;
+}
+__global__ __launch_bounds__(1024) void token_run_count_kernel(const int32_t* __restrict__ sorted_key, int64_t T, int chunk,
+                                                               int32_t* __restrict__ block_starts) {
+    __shared__ int wave_tot[16];
+    const int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const unsigned long long ball = __ballot(p < T && run_starts(sorted_key, p, chunk));
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = __popcll(ball);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int i = 0; i < 16; ++i) tot += wave_tot[i];
+        block_starts[blockIdx.x] = tot;
+    }
+}
+__global__ __launch_bounds__(1024) void token_run_number_kernel(const int32_t* __restrict__ sorted_key, int64_t T, int chunk,
+                                                                const int32_t* __restrict__ block_starts, int32_t* __restrict__ run_of) {
+    __shared__ int wave_tot[16];
+    __shared__ int before_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid == 0) {  // starts in the earlier blocks
+        int acc = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) acc += block_starts[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) before_s = acc;
+    }
+    const int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool st = p < T && run_starts(sorted_key, p, chunk);
+    const unsigned long long ball = __ballot(st);
+    if (lane == 0) wave_tot[wid] = __popcll(ball);
+    __syncthreads();
+    int run = before_s + __popcll(ball & ((2ull << lane) - 1ull)) - 1;  // starts at positions <= p, minus one
+    for (int w = 0; w < wid; ++w) run += wave_tot[w];
+    if (p < T) run_of[p] = run;
+}
+
 // run MACRO(NC) with NC = the smallest supported chunk count covering H
 #define CM3P_NC_SWITCH(H, MACRO)      \
     {                                 \
@@ -633,6 +792,36 @@ int cm3p_embed_ln_bwd_sorted(const float* dy, const int64_t* ids, const int64_t*
 #undef CM3P_EMB_SUM_NC
     CM3P_LAUNCH_CHECK();
     colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int64_t cm3p_token_order_workspace_ints(int64_t T, int64_t vocab) {
+    if (T <= 0 || vocab <= 0 || vocab + 2 > kOrdMaxKeys) return 0;  // 0: not covered (the caller sorts by other means)
+    const int64_t nblk = (T + kOrdBlock - 1) / kOrdBlock;
+    return (vocab + 2) * nblk + (vocab + 2) + T + (T + 1023) / 1024;
+}
+
+int cm3p_token_order(const int64_t* ids, int64_t T, int64_t vocab, int64_t* order, int32_t* run_of, int32_t* workspace, void* stream) {
+    CM3P_REQUIRE(ids && order && run_of && workspace && T > 0 && vocab > 0 && vocab + 2 <= kOrdMaxKeys && T < (int64_t(1) << 31));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = (int)((T + kOrdBlock - 1) / kOrdBlock), nkeys = (int)vocab + 2, nrb = (int)((T + 1023) / 1024);
+    int32_t* cnt = workspace;                               // [nkeys][nblk]
+    int32_t* key_start = cnt + (int64_t)nkeys * nblk;       // [nkeys]
+    int32_t* sorted_key = key_start + nkeys;                // [T]
+    int32_t* block_starts = sorted_key + T;                 // [nrb]
+    const size_t lds = (size_t)nkeys * sizeof(int);
+    token_hist_kernel<<<nblk, 256, lds, s>>>(ids, T, vocab, nblk, cnt);
+    CM3P_LAUNCH_CHECK();
+    token_key_prefix_kernel<<<(nkeys + 3) / 4, 256, 0, s>>>(cnt, key_start, nkeys, nblk);
+    CM3P_LAUNCH_CHECK();
+    exclusive_scan_kernel<<<1, 1024, 0, s>>>(key_start, nkeys);
+    CM3P_LAUNCH_CHECK();
+    token_scatter_kernel<<<nblk, 64, lds, s>>>(ids, T, vocab, nblk, cnt, key_start, order, sorted_key);
+    CM3P_LAUNCH_CHECK();
+    token_run_count_kernel<<<nrb, 1024, 0, s>>>(sorted_key, T, kEmbChunk, block_starts);
+    CM3P_LAUNCH_CHECK();
+    token_run_number_kernel<<<nrb, 1024, 0, s>>>(sorted_key, T, kEmbChunk, block_starts, run_of);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -86,19 +86,13 @@ def embed_ln_bwd(dy: Tensor, ids: Tensor, table: Tensor, weight: Tensor, mean: T
 def _embed_ln_bwd_sorted(dy, ids, table, weight, mean, rstd, padding_idx, slot, override):
     """The embedding backward without atomics (cm3p_embed_ln_bwd_sorted): tokens are visited in id order, every sum has a fixed
     order (reproducible bit for bit, which the atomic kernel is not) and tokens that share an id do not serialise on one row.
-    The sort and the run numbering are a dozen small torch kernels on the ids (no host read)."""
+    The sort and the run numbering are a counting sort in six small launches (cm3p_token_order; no host read)."""
     T = ids.numel()
     V, H = table.shape
     dev = table.device
     chunk = query("cm3p_embed_ln_bwd_sorted_chunk")
-    flat = ids.reshape(-1).to(torch.int64)
-    key = flat.clamp(-1, V)  # ids outside the table get no gradient: two keys for all of them bound the number of runs
-    sk, order = torch.sort(key, stable=True)
-    start = torch.ones(T, dtype=torch.bool, device=dev)
-    if T > 1:
-        start[1:] = sk[1:] != sk[:-1]
-    start |= (torch.arange(T, device=dev) % chunk) == 0
-    run_of = (torch.cumsum(start, 0) - 1).to(torch.int32)
+    flat = ids.reshape(-1).to(torch.int64).contiguous()
+    order, run_of = token_order(flat, V, chunk)
     R = min(T, V + 3 + T // chunk)
     run_rows = _empty((R, H), torch.float32, table)
     run_ids = torch.empty((R,), dtype=torch.int64, device=dev)
@@ -112,6 +106,29 @@ def _embed_ln_bwd_sorted(dy, ids, table, weight, mean, rstd, padding_idx, slot, 
          ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(d_table), ptr(d_ovr), ptr(run_rows), ptr(run_ids, torch.int64),
          ptr(part), ptr(dw), T, H, padding_idx, V, stream())
     return d_table, d_ovr, dw
+
+
+def token_order(flat_ids: Tensor, V: int, chunk: int):
+    """-> (order [T] int64: token indices by ascending clamp(id, -1, V), ties in token order; run_of [T] int32: run number of every
+    sorted position, a new run where the id changes and at every multiple of `chunk`).  cm3p_token_order (a counting sort on the
+    device); vocabularies beyond its histogram (V + 2 > 12288) and CM3P_TOKEN_ORDER=torch take the torch.sort / cumsum route that
+    defines the result."""
+    T = flat_ids.numel()
+    dev = flat_ids.device
+    n_ws = query("cm3p_token_order_workspace_ints", T, V) if os.environ.get("CM3P_TOKEN_ORDER", "hip") != "torch" else 0
+    if n_ws > 0:
+        order = torch.empty((T,), dtype=torch.int64, device=dev)
+        run_of = torch.empty((T,), dtype=torch.int32, device=dev)
+        ws = torch.empty((n_ws,), dtype=torch.int32, device=dev)
+        call("cm3p_token_order", ptr(flat_ids, torch.int64), T, V, ptr(order, torch.int64), ptr(run_of, torch.int32), ptr(ws, torch.int32), stream())
+        return order, run_of
+    key = flat_ids.clamp(-1, V)  # ids outside the table get no gradient: two keys for all of them bound the number of runs
+    sk, order = torch.sort(key, stable=True)
+    start = torch.ones(T, dtype=torch.bool, device=dev)
+    if T > 1:
+        start[1:] = sk[1:] != sk[:-1]
+    start |= (torch.arange(T, device=dev) % chunk) == 0
+    return order, (torch.cumsum(start, 0) - 1).to(torch.int32)
 
 
 def audio_slots(ids: Tensor, audio_token_id: int):

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 13
+#define CM3P_ABI_VERSION 14
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -83,6 +83,14 @@ int cm3p_embed_ln_bwd_sorted(const float* dy, const int64_t* ids, const int64_t*
                              int table_dtype, const int32_t* slot, const void* override_rows, int override_dtype, const float* weight,
                              const float* mean, const float* rstd, float* d_table, float* d_override, float* run_rows, int64_t* run_ids,
                              float* dw_partial, float* dw, int64_t T, int H, int64_t padding_idx, int64_t vocab, void* stream);
+
+/* The two index arrays cm3p_embed_ln_bwd_sorted takes, made on the device from the ids alone (a stable counting sort; replaces the
+ * torch.sort / cumsum sequence of r03 - integer bookkeeping with no counterpart in the reference, whose nn.Embedding backward
+ * (TF:models/modernbert/modeling_modernbert.py:64-71) scatters with atomics): order[T] int64 and run_of[T] int32 exactly as specified
+ * there, keys = clamp(ids, -1, vocab).  workspace: cm3p_token_order_workspace_ints(T, vocab) int32 values; that query returns 0 when
+ * the vocabulary is too large for the kernel's per-block histogram (vocab + 2 > 12288): the caller then sorts by other means. */
+int64_t cm3p_token_order_workspace_ints(int64_t T, int64_t vocab);
+int cm3p_token_order(const int64_t* ids, int64_t T, int64_t vocab, int64_t* order, int32_t* run_of, int32_t* workspace, void* stream);
 
 /* slot[t] = rank of token t among the tokens equal to audio_token_id, in row-major (b, s) order, else -1;
  * count[0] = how many there are.  The integer side of ref:cm3p/modeling_cm3p.py:604-605 (bit-exact). */

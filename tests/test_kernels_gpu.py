@@ -202,6 +202,35 @@ def test_embed_ln_with_audio_override(K, monkeypatch, impl):
     _assert_close(dw, wr.grad, 1e-3, 1e-5, "embed dw")
 
 
+@pytest.mark.parametrize("T,V,skew", [(1, 5, 0.0), (63, 7, 0.0), (64, 300, 0.3), (1025, 3167, 0.0), (40000, 300, 0.3), (131072, 3167, 0.4), (70001, 12286, 0.9)])
+def test_token_order_is_the_stable_sort_of_the_ids(K, monkeypatch, T, V, skew):
+    """cm3p_token_order (a counting sort in six launches) against what defines it: torch.sort(stable=True) of clamp(ids, -1, V) and the
+    run numbering by cumsum.  Integer work: bit-exact.  Shapes: one token, less than a wave, exactly one chunk, a block boundary + 1,
+    one id holding 30-90 % of the tokens, the C2 token count at the beatmap vocabulary, the largest vocabulary the kernel covers; ids
+    outside the table on both sides."""
+    g = torch.Generator().manual_seed(T + V)
+    ids = torch.randint(0, V, (T,), generator=g)
+    if skew:
+        ids[torch.rand(T, generator=g) < skew] = V // 3
+    if T > 8:
+        ids[3], ids[5], ids[T - 1], ids[T // 2] = -7, V, V + 12345, -1
+    ids = ids.to(DEV)
+    monkeypatch.setenv("CM3P_TOKEN_ORDER", "hip")
+    assert K.query("cm3p_token_order_workspace_ints", T, V) > 0
+    order, run_of = K.token_order(ids, V, 64)
+    monkeypatch.setenv("CM3P_TOKEN_ORDER", "torch")
+    order_t, run_of_t = K.token_order(ids, V, 64)
+    assert order.dtype == torch.int64 and run_of.dtype == torch.int32
+    assert torch.equal(order, order_t) and torch.equal(run_of, run_of_t)
+
+
+def test_token_order_leaves_large_vocabularies_to_the_torch_route(K):
+    assert K.query("cm3p_token_order_workspace_ints", 1000, 12287) == 0  # vocab + 2 > 12288 keys: not covered
+    ids = torch.randint(0, 50000, (5000,), device=DEV)
+    order, run_of = K.token_order(ids, 50000, 64)
+    assert torch.equal(ids[order], torch.sort(ids, stable=True)[0]) and int(run_of[0]) == 0
+
+
 def test_embedding_backward_in_id_order_is_reproducible_and_matches_autograd(K, monkeypatch):
     """The default embedding backward visits the tokens sorted by id (no atomics): 40000 tokens over a 300-row table with one id
     taking 30 % of them (runs that span many 64-token chunks), the padding row, ids outside the table (no gradient, no fault) and

@@ -22,15 +22,18 @@ def impl(name):
     os.environ["CM3P_GEMM_IMPL"] = name
 
 
+IMPLS = ("256", "8p")  # --impls: any of 128 (gemm.hip's 128 x 128 kernel for every shape), 256 (gemm256.hip), 8p (gemm8p.hip, default)
+
+
 def ab(label, fn, flops, rounds, iters):
-    res = {"256": [], "8p": []}
+    res = {n: [] for n in IMPLS}
     for _ in range(rounds):
-        for name in ("256", "8p"):
+        for name in IMPLS:
             impl(name)
             res[name].append(timeit(fn, iters))
-    a, b = res["256"], res["8p"]
-    print(f"{label:34s} 256: {statistics.median(a):7.3f} ms (min {min(a):7.3f}) {flops / statistics.median(a) / 1e9:7.1f} TF/s | "
-          f"8p: {statistics.median(b):7.3f} ms (min {min(b):7.3f}) {flops / statistics.median(b) / 1e9:7.1f} TF/s | x{statistics.median(a) / statistics.median(b):.3f}", flush=True)
+    base = statistics.median(res[IMPLS[0]])
+    print(f"{label:34s} " + " | ".join(f"{n}: {statistics.median(v):7.3f} ms (min {min(v):7.3f}) {flops / statistics.median(v) / 1e9:7.1f} TF/s x{base / statistics.median(v):.3f}"
+                                       for n, v in res.items()), flush=True)
 
 
 def main():
@@ -38,7 +41,10 @@ def main():
     ap.add_argument("what", nargs="*", default=["check", "cube", "step"])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--impls", default="256,8p")
     args = ap.parse_args()
+    global IMPLS
+    IMPLS = tuple(args.impls.split(","))
     g = torch.Generator(device=DEV).manual_seed(0)
     uni = lambda *s: (torch.rand(*s, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
     rnd = lambda *s: torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
