@@ -39,6 +39,7 @@ SIGNATURES = {
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],
     "cm3p_gemm_wgrad_splits": [_L, _L, _L],
     "cm3p_build_ablation_flags": [],
+    "cm3p_debug_set_dma_audit": [_P],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
     "cm3p_cast_f32_bf16_t": [_P, _P, _P, _L, _L, _P],
     "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],

@@ -69,7 +69,42 @@ def build(force: bool = False, verbose: bool = True, check_isa: bool = True) -> 
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_audit(force=force, verbose=verbose)
     return LIB
+
+
+# The bounds-audit twin of the library (csrc/common.h, CM3P_DMA_AUDIT): the objects that stage operands by LDS-DMA are compiled a second
+# time with the recording hooks in; everything else is shared with the shipped library.  Debug artefact, loaded only by
+# tests/test_dma_audit_gpu.py (cm3p_build_ablation_flags() is non-zero for it, so _lib.load() refuses it as a product library).
+AUDIT_SOURCES = ["gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_bwd_fused.hip"]
+AUDIT_LIB = os.path.join(CSRC, "libcm3p_hip_audit.so")
+
+
+def build_audit(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "..", "..", "include", "cm3p_hip.h")]
+    objs, procs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if src not in AUDIT_SOURCES:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+            continue
+        o = os.path.join(CSRC, src.replace(".hip", ".audit.o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc, *[f for f in FLAGS if f != "-Wall"], *EXTRA_FLAGS.get(src, []), "-DCM3P_DMA_AUDIT=1", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src} (audit build)")
+    if force or procs or _stale(AUDIT_LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", AUDIT_LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return AUDIT_LIB
 
 
 if __name__ == "__main__":

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     auto dma_tile = [&](int t) {
         const uint32_t slot = (uint32_t)((t - t_lo) & (kDqSlots - 1)) * kDqStage;
         dma.rows(m0_k + slot, kbase, ldb, t * 64, S);
-        dma.rows(m0_k + slot + 8192u, vbase, ldb, t * 64, S);
+        dma.rows(m0_k + slot + 8192u, vbase, ldb, t * 64, S, CM3P_AUD_T1);
         if constexpr (MASK) dma_ubyte64(lds0 + slot + 16384u, km, (uint32_t)min(t * 64 + lane, S - 1));
     };
     for (int t = t_lo; t <= min(t_hi, t_lo + 2); ++t) dma_tile(t);
@@ -489,11 +489,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     auto dma_tile = [&](int t) {
         const uint32_t slot = (uint32_t)((t - t_lo) & (kDkvSlots - 1)) * kDkvStage;
         dma.rows(m0_q + slot, qbase, (int)ld * 2, t * 64, S);
-        dma.rows(m0_q + slot + 8192u, dobase, (int)ldo * 2, t * 64, S);
+        dma.rows(m0_q + slot + 8192u, dobase, (int)ldo * 2, t * 64, S, CM3P_AUD_T1);
         if (wid == 0) {
             const uint32_t so = (uint32_t)(min(t * 64 + lane, S - 1) * 4);
             dma_dword64(lds0 + slot + 16384u, lse_bh, so);
-            dma_dword64(lds0 + slot + 16384u + 256u, dlt_bh, so);
+            dma_dword64(lds0 + slot + 16384u + 256u, dlt_bh, so, CM3P_AUD_S1);
         }
     };
     for (int t = t_lo; t <= min(t_hi, (CM3P_BABL & 4) ? t_lo - 1 : t_lo + 2); ++t) dma_tile(t);
@@ -809,3 +809,6 @@ int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, 
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
 int cm3p_ablation_flags_attention() { return (CM3P_BABL); }
+#if CM3P_DMA_AUDIT
+int cm3p_audit_set_attention(void* buf) { return cm3p_audit_set_local(buf); }
+#endif

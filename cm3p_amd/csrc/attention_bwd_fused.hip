@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     };
     auto dma_rows = [&](int slot) {
         const uint32_t m0v = m0_tile + (uint32_t)slot * kFStage;
+        CM3P_AUDIT(CM3P_AUD_T0, q_dma + dv0, 16);  // (bases are kept 3 KiB low, source offsets (3 - piece) KiB high, instruction offsets piece KiB)
+        CM3P_AUDIT(CM3P_AUD_T0, q_dma + dv1 + 1024, 16);
+        CM3P_AUDIT(CM3P_AUD_T1, do_dma + dv2 + 2048, 16);
+        CM3P_AUDIT(CM3P_AUD_T1, do_dma + dv3 + 3072, 16);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, %5\n\t"
                      "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     };
     auto dma_stat = [&](int slot) {
         const uint32_t m0v = m0_stat + (uint32_t)slot * kFStage;
+        CM3P_AUDIT(CM3P_AUD_S0, reinterpret_cast<const char*>(stat_bh) + dvs, 4);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(dvs), "s"(stat_bh) : "memory", "m0");
     };
 
@@ -786,3 +791,6 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
 int cm3p_ablation_flags_attention_bwd_fused() { return (CM3P_FABL); }
+#if CM3P_DMA_AUDIT
+int cm3p_audit_set_attention_bwd_fused(void* buf) { return cm3p_audit_set_local(buf); }
+#endif

@@ -193,20 +193,25 @@ struct TileDma {
     }
     // rows r0 + prow (clamped to limit - 1) of the matrix at `base` (row stride ldb BYTES) -> LDS address m0v (+ 2 KiB per wave
     // already included by the caller)
-    __device__ __forceinline__ void rows(uint32_t m0v, const void* base, int ldb, int r0, int limit) const {
+    // (audit_id: which operand this is to the bounds audit, common.h)
+    __device__ __forceinline__ void rows(uint32_t m0v, const void* base, int ldb, int r0, int limit, int audit_id = CM3P_AUD_T0) const {
         const uint32_t v0 = (uint32_t)(min(r0 + prow0, limit - 1) * ldb + pc0 + 1024);
         const uint32_t v1 = (uint32_t)(min(r0 + prow1, limit - 1) * ldb + pc1);
         const char* b = static_cast<const char*>(base) - 1024;
+        CM3P_AUDIT(audit_id, b + v0, 16);          // first piece: base + row * pitch + chunk
+        CM3P_AUDIT(audit_id, b + v1 + 1024, 16);   // second piece: the instruction offset moves the global address too
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024" ::"s"(m0v), "v"(v0),
                      "v"(v1), "s"(b)
                      : "memory", "m0");
     }
 };
 // 64 consecutive floats / bytes (one per lane, index clamped by the caller) -> 64 dwords at LDS address m0v (bytes zero-extended)
-__device__ __forceinline__ void dma_dword64(uint32_t m0v, const void* base, uint32_t byte_off) {
+__device__ __forceinline__ void dma_dword64(uint32_t m0v, const void* base, uint32_t byte_off, int audit_id = CM3P_AUD_S0) {
+    CM3P_AUDIT(audit_id, static_cast<const char*>(base) + byte_off, 4);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"(byte_off), "s"(base) : "memory", "m0");
 }
-__device__ __forceinline__ void dma_ubyte64(uint32_t m0v, const void* base, uint32_t byte_off) {
+__device__ __forceinline__ void dma_ubyte64(uint32_t m0v, const void* base, uint32_t byte_off, int audit_id = CM3P_AUD_S0) {
+    CM3P_AUDIT(audit_id, static_cast<const char*>(base) + byte_off, 1);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2" ::"s"(m0v), "v"(byte_off), "s"(base) : "memory", "m0");
 }
 // wait until at most n of this wave's vector-memory operations are outstanding (n in {0, 4, 5, 6, 8, 10, 12}: the immediates the

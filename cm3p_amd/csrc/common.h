@@ -70,6 +70,44 @@ __device__ __forceinline__ __attribute__((ext_vector_type(4))) float gload16f(co
     else return *static_cast<const f4*>(p);
 }
 
+// ---- bounds audit of the LDS-DMA streams (debug builds only: -DCM3P_DMA_AUDIT=1, libcm3p_hip_audit.so) -------------------------
+// An LDS-DMA load has no destination register and no bounds check, and a stray READ changes nothing a parity test can see unless it
+// crosses into an unmapped page (the r03 fault of gemm8p's staging stream was exactly that).  In an audit build every staging
+// helper reports the lowest and highest global byte address its wave is about to read, per operand id, to a caller-owned buffer
+// (cm3p_debug_set_dma_audit); tests/test_dma_audit_gpu.py runs the edge shapes and asserts that every address lies inside the
+// tensor the caller passed.  The shipped library is built without it (cm3p_build_ablation_flags() bit 5 says which one this is).
+//   ids: 0 GEMM A operand, 1 GEMM B operand, 2 / 3 first / second tile matrix of an attention ring (K, V or Q, dO),
+//        4 / 5 per-row statistics or mask rows (lse or mask; delta)
+#ifndef CM3P_DMA_AUDIT
+#define CM3P_DMA_AUDIT 0
+#endif
+enum { CM3P_AUD_A = 0, CM3P_AUD_B = 1, CM3P_AUD_T0 = 2, CM3P_AUD_T1 = 3, CM3P_AUD_S0 = 4, CM3P_AUD_S1 = 5, CM3P_AUD_SLOTS = 8 };
+#if CM3P_DMA_AUDIT
+static __device__ unsigned long long* cm3p_audit_buf = nullptr;  // [CM3P_AUD_SLOTS][2]: lowest first byte, highest last byte (one copy per object file)
+static inline int cm3p_audit_set_local(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(cm3p_audit_buf), &buf, sizeof(buf)) == hipSuccess ? CM3P_OK : CM3P_ERR_LAUNCH;
+}
+// every lane passes the address of the first byte it reads and how many bytes (all lanes of the wave are active at the call sites)
+__device__ __forceinline__ void cm3p_audit(int id, const void* first_byte, int bytes) {
+    unsigned long long* buf = cm3p_audit_buf;
+    if (!buf) return;
+    unsigned long long lo = (unsigned long long)(uintptr_t)first_byte, hi = lo + (unsigned long long)bytes - 1ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(buf + 2 * id, lo);
+        atomicMax(buf + 2 * id + 1, hi);
+    }
+}
+#define CM3P_AUDIT(id, addr, bytes) cm3p_audit((id), (addr), (bytes))
+#else
+#define CM3P_AUDIT(id, addr, bytes) ((void)0)
+#endif
+
 // Every extern "C" entry point ends with this: kernels never throw, launch errors become a return code.
 #define CM3P_LAUNCH_CHECK()                                         \
     do {                                                            \

@@ -301,12 +301,31 @@ int cm3p_ablation_flags_attention_bwd();
 int cm3p_ablation_flags_attention_bwd_fused();
 int cm3p_ablation_flags_gemm256();
 int cm3p_ablation_flags_gemm8p();
+#if CM3P_DMA_AUDIT
+int cm3p_audit_set_gemm8p(void*);
+int cm3p_audit_set_gemm256(void*);
+int cm3p_audit_set_attention(void*);
+int cm3p_audit_set_attention_bwd_fused(void*);
+#endif
 
 extern "C" {
 
 int cm3p_build_ablation_flags(void) {
     return (cm3p_ablation_flags_attention() != 0) | (cm3p_ablation_flags_attention_bwd() != 0) << 1 | (cm3p_ablation_flags_attention_bwd_fused() != 0) << 2 |
-           (cm3p_ablation_flags_gemm256() != 0) << 3 | (cm3p_ablation_flags_gemm8p() != 0) << 4;
+           (cm3p_ablation_flags_gemm256() != 0) << 3 | (cm3p_ablation_flags_gemm8p() != 0) << 4 | (CM3P_DMA_AUDIT != 0) << 5;
+}
+
+int cm3p_debug_set_dma_audit(void* buf) {
+#if CM3P_DMA_AUDIT
+    int rc = cm3p_audit_set_gemm8p(buf);
+    if (rc == CM3P_OK) rc = cm3p_audit_set_gemm256(buf);
+    if (rc == CM3P_OK) rc = cm3p_audit_set_attention(buf);
+    if (rc == CM3P_OK) rc = cm3p_audit_set_attention_bwd_fused(buf);
+    return rc;
+#else
+    (void)buf;
+    return CM3P_ERR_INVALID;  // this library was built without the audit hooks
+#endif
 }
 
 int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K) {

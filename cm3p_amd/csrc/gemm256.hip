@@ -81,7 +81,9 @@ struct Stager {
     }
     // one m0 write for the wave's four consecutive 1-KiB pieces: the instruction offset moves the LDS address (and the global
     // address, which is why src[i] is kept i KiB low - see init)
-    __device__ __forceinline__ void issue(char* image, int wid) {
+    __device__ __forceinline__ void issue(char* image, int wid, int audit_id = CM3P_AUD_A) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) CM3P_AUDIT(audit_id, src[i] + (i & 3) * 512, 16);  // (src[i] is kept (i & 3) KiB low, see init)
 #pragma unroll
         for (int g4 = 0; g4 < kPieces / 4; ++g4) {
             const uint32_t m0v = __builtin_amdgcn_readfirstlane(
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
     sb.init(B, ldb, n0, N, kbeg, wid, lane);
     int stage = 0;
     sa.issue(smem, wid);
-    sb.issue(smem + kOperandBytes, wid);
+    sb.issue(smem + kOperandBytes, wid, CM3P_AUD_B);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
             auto issue_at = [&](int g) {
                 if (steady && g == ((A_KC && kWN == 4 && wm == 1) ? 0 : -1)) {
                     sa.issue(nxt, wid);
-                    if constexpr (!(CM3P_G256_ABL & 1)) sb.issue(nxt + kOperandBytes, wid);
+                    if constexpr (!(CM3P_G256_ABL & 1)) sb.issue(nxt + kOperandBytes, wid, CM3P_AUD_B);
                 }
             };
             if (!steady && has_next) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kThreads, kWN == 4 ? 2 : 1) void gemm256_kernel(con
                 sa.init(A, lda, m0n, M, kbegn, wid, lane);
                 sb.init(B, ldb, n0n, N, kbegn, wid, lane);
                 sa.issue(nxt, wid);
-                sb.issue(nxt + kOperandBytes, wid);
+                sb.issue(nxt + kOperandBytes, wid, CM3P_AUD_B);
             }
             issue_at(-1);
             const char* ia = cur;
@@ -455,3 +457,6 @@ int cm3p_gemm256_dispatch(const void* A, const void* B, void* C, const float* R,
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
 int cm3p_ablation_flags_gemm256() { return (CM3P_G256_ABL) | ((CM3P_G256_WN != 4) << 8); }
+#if CM3P_DMA_AUDIT
+int cm3p_audit_set_gemm256(void* buf) { return cm3p_audit_set_local(buf); }
+#endif

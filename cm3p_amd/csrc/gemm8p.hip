@@ -52,8 +52,9 @@ enum { kAL = 0, kAH = 1, kBL = 2, kBH = 3 };
 __host__ __device__ constexpr int slot_off(int par, int kind) { return (par * 4 + kind) * kHalf; }
 
 // one 1-KiB LDS-DMA piece: global address = sbase (SGPR pair) + voff (VGPR, bytes), LDS address = ldsw + IMM + 16 * lane
-template <int IMM>
+template <int IMM, int AUD = CM3P_AUD_A>
 __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_t ldsw) {
+    CM3P_AUDIT(AUD, sbase + voff, 16);
     if constexpr (CM3P_G8P_ABL & 64) {
         asm volatile("" ::"v"(voff), "s"(sbase), "s"(ldsw));
         return;
@@ -141,8 +142,8 @@ struct Operand {
     }
     template <int SLOT>
     __device__ __forceinline__ void stage(int h, uint32_t lds) const {
-        glds_s<SLOT>(voff[h], p[h][0], lds);
-        glds_s<SLOT + 1024>(voff[h], p[h][1], lds);
+        glds_s<SLOT, IS_A ? CM3P_AUD_A : CM3P_AUD_B>(voff[h], p[h][0], lds);
+        glds_s<SLOT + 1024, IS_A ? CM3P_AUD_A : CM3P_AUD_B>(voff[h], p[h][1], lds);
     }
     // fragment t (16 idx) of this wave's share of a half-tile, k sub-step kk (32 deep); `off` = parity offset + slot offset
     __device__ __forceinline__ bf16x8 frag(const char* smem, int off, int t, int kk) const {
@@ -696,3 +697,6 @@ int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, 
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
 int cm3p_ablation_flags_gemm8p() { return (CM3P_G8P_ABL); }
+#if CM3P_DMA_AUDIT
+int cm3p_audit_set_gemm8p(void* buf) { return cm3p_audit_set_local(buf); }
+#endif

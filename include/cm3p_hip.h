@@ -124,6 +124,14 @@ int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_
  * for results (cm3p_amd/_lib.py refuses to load anything else; tests/test_cabi.py). */
 int cm3p_build_ablation_flags(void);
 
+/* Debug builds only (libcm3p_hip_audit.so, -DCM3P_DMA_AUDIT=1; bit 5 of cm3p_build_ablation_flags): every LDS-DMA staging helper of the
+ * GEMM and attention kernels then records, per operand id (csrc/common.h: 0 / 1 GEMM A / B, 2 / 3 the two tile matrices of an attention
+ * ring, 4 / 5 statistics or mask rows), the lowest first byte and the highest last byte it reads into buf[id][0] / buf[id][1]
+ * (uint64, atomicMin / atomicMax: the caller initialises them to ~0 and 0); NULL switches the recording off.  Not stream-ordered: call
+ * it between synchronised launches.  The shipped library returns CM3P_ERR_INVALID.  tests/test_dma_audit_gpu.py asserts on the edge
+ * shapes that every recorded address lies inside the tensor the caller handed over (the r03 over-read of the GEMM's staging stream). */
+int cm3p_debug_set_dma_audit(void* buf);
+
 /* Fused Wqkv projection + rotary embedding: qkv[M, N] (bf16) = x[M, K] Wqkv[N, K]^T with apply_rotary_pos_emb applied to the
  * first rope_cols (= 2H: the q and k thirds) columns (TF:...modeling_modernbert.py:271-280).  The 256 x 256 kernel rotates the
  * bf16-rounded projection in fp32 while it stores the staged rows (what the reference's autocast path computes: rotary on the
