@@ -33,7 +33,7 @@ def test_every_lds_dma_stream_stays_inside_its_operand():
     bad = [r for r in rows if r.get("ok") is False]
     assert p.returncode == 0 and not bad, (bad[:5], p.stderr[-2000:])
     cases = [r for r in rows if "case" in r]
-    assert len(cases) >= 50 and rows[-1] == {"failed": 0}
+    assert len(cases) >= 40 and rows[-1] == {"failed": 0}
     # both big-shape GEMM kernels, both attention backward families and the packed-sequence forms were exercised
     names = " | ".join(r["case"] for r in cases)
     for needle in ("gemm 8p fwd", "gemm 256 fwd", "wgrad", "dgrad", "RoPE", "GeGLU", "batched", "sliding-window backward stage 1", "stage 2",

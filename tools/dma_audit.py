@@ -63,7 +63,7 @@ def gemm_cases():
     for impl in ("8p", "256"):
         os.environ["CM3P_GEMM_IMPL"] = impl
         # forward orientation (both operands k-contiguous): edge tiles in both extents, one k-tile, more work items than workgroups
-        for (M, N, Kd) in ((8200, 2312, 128), (256 * 30, 256 * 7, 64), (12800, 768, 192), (65536 + 64, 1152, 768), (70000, 776, 128)):
+        for (M, N, Kd) in ((8200, 2312, 128), (256 * 30, 256 * 7, 64), (25600, 768, 192), (65536 + 64, 1152, 768), (70000, 776, 128)):
             a, w, c = bf(M, Kd), bf(N, Kd), torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
             audited(f"gemm {impl} fwd bf16 [{M}x{N}x{Kd}]",
                     lambda: call("cm3p_gemm_bf16", ptr(a), ptr(w), ptr(c), None, M, N, Kd, Kd, Kd, N, 1, 1, 0, 1, None, stream()), {0: a, 1: w})
@@ -73,7 +73,7 @@ def gemm_cases():
         audited(f"gemm {impl} fwd fp32+resid [{M}x{N}x{Kd}]",
                 lambda: call("cm3p_gemm_bf16", ptr(a), ptr(w), ptr(c32), ptr(r), M, N, Kd, Kd, Kd, N, 1, 1, 2, 1, None, stream()), {0: a, 1: w})
         # input gradient through the k-strided weight: dx[M, N] = dy[M, K] W[K, N]  (b_kc = 0, ldb = N)
-        for (M, N, Kd) in ((8200, 776, 2304), (40960, 1152, 768)):
+        for (M, N, Kd) in ((16400, 776, 2304), (40960, 1152, 768)):
             dy, w, c = bf(M, Kd), bf(Kd, N), torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
             audited(f"gemm {impl} dgrad (B k-strided) [{M}x{N}x{Kd}]",
                     lambda: call("cm3p_gemm_bf16", ptr(dy), ptr(w), ptr(c), None, M, N, Kd, Kd, N, N, 1, 0, 0, 1, None, stream()), {0: dy, 1: w})
