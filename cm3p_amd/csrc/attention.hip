@@ -277,19 +277,17 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 constexpr int kDqStage = 2 * 8192 + 256;  // K image, V image, one validity dword per key
 constexpr int kDqSlots = 4;               // LDS-DMA ring: tile t+3 is requested while tile t is consumed
 
-template <bool PRE, bool MASK>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                             const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
-                                                             float* __restrict__ delta,
-                                                             uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                             int Smax, int nh, int window, float scale,
-                                                             const float* __restrict__ rope_cos,
-                                                             const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// EXT_DELTA: delta[b, h, q] was written by attn_delta_kernel before this launch (the merged launch below); otherwise this sweep
+// computes it for its own rows from O and dO and publishes it for the dK / dV kernel that follows.
+template <bool PRE, bool MASK, bool EXT_DELTA>
+__device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, int b, const uint16_t* __restrict__ qkv,
+                                              const uint16_t* __restrict__ d_o, const uint16_t* __restrict__ o_rows,
+                                              const float* __restrict__ lse, float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                              const uint8_t* __restrict__ kmask, int Smax, int nh, int window, float scale,
+                                              const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                              int64_t pos_batch_stride, VarLen vl) {
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int qblk, head, b;
-    decode_block((Smax + 127) / 128, nh, qblk, head, b);
     const int Q0 = qblk * 128;
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
@@ -347,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     // delta[q] = sum_d dO[q, d] O[q, d]: this lane holds half of its query's dO row already; the other half sits 32 lanes
     // away.  Written out for the dK/dV kernel, which runs after this one (no separate delta launch, one less pass over dO).
     float dlt = 0.f;
-    {
+    if constexpr (EXT_DELTA) {
+        dlt = delta[stat];
+    } else {
         const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -433,6 +433,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     store_rows32(smem + 4608 * wid, dq[0], dq[1], scale, dqkv + (sv.row0 + q0) * ld + head * 64, ld, S - q0, lane);
 }
 
+template <bool PRE, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                             const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
+                                                             float* __restrict__ delta,
+                                                             uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                             int Smax, int nh, int window, float scale,
+                                                             const float* __restrict__ rope_cos,
+                                                             const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int qblk, head, b;
+    decode_block((Smax + 127) / 128, nh, qblk, head, b);
+    band_dq_block<PRE, MASK, false>(smem, qblk, head, b, qkv, d_o, o_rows, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin,
+                                    pos_batch_stride, vl);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dK, dV: one workgroup = 4 waves = 128 keys of one (batch, head); each wave owns 32 keys (key on the lane) and keeps
 // dK^T, dV^T (64 x 32 each) in accumulators while the workgroup sweeps query tiles of 64 rows.
@@ -443,17 +458,14 @@ constexpr int kDkvStage = 2 * 8192 + 512;  // Q image, dO image, the rows' lse a
 constexpr int kDkvSlots = 4;               // LDS-DMA ring, as in the dq kernel
 
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
-                                                              int Smax, int nh, int window, float scale,
-                                                              const float* __restrict__ rope_cos,
-                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void band_dkv_block(char* smem, int kblk, int head, int b, const uint16_t* __restrict__ qkv,
+                                               const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                               const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                               const uint8_t* __restrict__ kmask, int Smax, int nh, int window, float scale,
+                                               const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                               int64_t pos_batch_stride, VarLen vl) {
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int kblk, head, b;
-    decode_block((Smax + 127) / 128, nh, kblk, head, b);
     const int K0 = kblk * 128;
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
@@ -620,6 +632,76 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     }
 }
 
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask,
+                                                              int Smax, int nh, int window, float scale,
+                                                              const float* __restrict__ rope_cos,
+                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int kblk, head, b;
+    decode_block((Smax + 127) / 128, nh, kblk, head, b);
+    band_dkv_block<PRE>(smem, kblk, head, b, qkv, d_o, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin, pos_batch_stride, vl);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sliding-window backward as ONE launch (r04).  The pair above reads q, k, v and dO twice (2.96 GB per C2 layer against 1.61 GB
+// algorithmic, r03 PMC) and both kernels already run at the rate their own traffic allows.  Here the dQ sweep and the dK / dV
+// sweep of the SAME 128 rows are neighbouring workgroups of one grid (logical id 2 n: queries [128 n, 128 n + 128) as the dQ
+// sweep; 2 n + 1: the same rows as keys), so they are resident on one XCD at the same time (decode_block) and whichever comes
+// second finds the K / V / Q / dO rows in that XCD's L2.  The sweeps themselves are the two kernels above, unchanged: same
+// products, same order, bit-identical results.  delta = rowsum(dO o O) can then no longer come from the dQ sweep (the dK / dV
+// sweep of a neighbouring workgroup would read it before it is written): attn_delta_kernel computes it first, in the dQ sweep's
+// summation order.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kBandLds = kDqSlots * kDqStage > kDkvSlots * kDkvStage ? kDqSlots * kDqStage : kDkvSlots * kDkvStage;
+
+template <bool PRE, bool MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_band_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                               const float* __restrict__ lse, float* __restrict__ delta,
+                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
+                                                               int nh, int window, float scale, const float* __restrict__ rope_cos,
+                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int blk2, head, b;
+    decode_block(2 * ((Smax + 127) / 128), nh, blk2, head, b);
+    if (blk2 & 1)
+        band_dkv_block<PRE>(smem, blk2 >> 1, head, b, qkv, d_o, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin, pos_batch_stride, vl);
+    else
+        band_dq_block<PRE, MASK, true>(smem, blk2 >> 1, head, b, qkv, d_o, nullptr, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos,
+                                       rope_sin, pos_batch_stride, vl);
+}
+
+// delta[b, h, q] = sum_d dO[q, d] O[q, d] in the dQ sweep's order: lane (row, half) adds its 32 products (dims 16 s + 8 half + j, s and
+// then j ascending) and the two halves are added last.  One workgroup = 128 rows of one (batch, head), two threads per row.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o_rows, const uint16_t* __restrict__ d_o,
+                                                         float* __restrict__ delta, int Smax, int nh, VarLen vl) {
+    int blk, head, b;
+    decode_block((Smax + 127) / 128, nh, blk, head, b);
+    const SeqView sv(vl, b, head, Smax, nh);
+    const int S = sv.S;
+    const int row = blk * 128 + (threadIdx.x >> 1), hh = threadIdx.x & 1;
+    if (blk * 128 >= S) return;
+    const int rc = row < S ? row : S - 1;
+    const int64_t ldo = (int64_t)nh * 64;
+    const uint16_t* po = o_rows + (sv.row0 + rc) * ldo + head * 64 + 8 * hh;
+    const uint16_t* pg = d_o + (sv.row0 + rc) * ldo + head * 64 + 8 * hh;
+    bf16x8 of[4], gf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        of[s] = *reinterpret_cast<const bf16x8*>(po + 16 * s);
+        gf[s] = *reinterpret_cast<const bf16x8*>(pg + 16 * s);
+    }
+    float dlt = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dlt += (float)of[s][j] * (float)gf[s][j];
+    dlt += __shfl_xor(dlt, 1, 64);
+    if (hh == 0 && row < S) delta[sv.stat0 + row] = dlt;
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // output_attentions: the probabilities themselves, [B, nh, S, S] fp32 - what the reference returns when a caller asks for
@@ -710,6 +792,28 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
         return cm3p_launch_attn_bwd_global(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, scale, cos_tab, sin_tab, pos_batch_stride,
                                            vl.cu, vl.total, stages, pre, s);
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
+    // both stages in one call: the merged launch (CM3P_ATTN_BAND_MERGED=0: the two-kernel pair, bit-identical results)
+    const char* env_m = getenv("CM3P_ATTN_BAND_MERGED");  // (read per call: one process can A/B)
+    const bool merged_ok = !(env_m && env_m[0] == '0');
+    if (stages == (CM3P_ATTN_BWD_DQ | CM3P_ATTN_BWD_DKV) && merged_ok) {
+        static const bool attr = [] {
+            const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, false>),
+                                reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, false>)};
+            for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kBandLds);
+            return true;
+        }();
+        (void)attr;
+        attn_delta_kernel<<<grid, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, S, nh, vl);
+        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
+        const dim3 grid2(2 * grid.x);
+#define CM3P_BAND_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
+        if (pre && key_mask) attn_bwd_band_kernel<true, true><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
+        else if (pre) attn_bwd_band_kernel<true, false><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
+        else if (key_mask) attn_bwd_band_kernel<false, true><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
+        else attn_bwd_band_kernel<false, false><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
+#undef CM3P_BAND_ARGS
+        return CM3P_OK;
+    }
     if (stages & CM3P_ATTN_BWD_DQ) {
 #define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
         static const bool attr = [] {

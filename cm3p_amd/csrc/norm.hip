@@ -77,11 +77,13 @@ template <bool X_BF16, int NC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ y32, uint16_t* __restrict__ y16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int64_t rows, int H, float eps) {
+                                                            int64_t rows, int H, float eps, int reverse) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t row = wave; row < rows; row += nwaves) {
+    for (int64_t it = wave; it < rows; it += nwaves) {
+        // reverse: the last rows first - what the kernel before this one wrote last is what the Infinity Cache still holds
+        const int64_t row = reverse ? rows - 1 - it : it;
         RowRegs<NC> r;
         const void* src = X_BF16 ? (const void*)(static_cast<const uint16_t*>(x) + row * H)
                                  : (const void*)(static_cast<const float*>(x) + row * H);
@@ -667,11 +669,13 @@ int cm3p_layernorm_fwd(const void* x, int x_dtype, const float* weight, float* y
     CM3P_REQUIRE(x_dtype == CM3P_F32 || x_dtype == CM3P_BF16);
     if (rows == 0) return CM3P_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const char* env_r = getenv("CM3P_LN_REVERSE");  // development probe (tools/mall_order_probe.py): row order of the sweep
+    const int reverse = env_r && env_r[0] == '1';
 #define CM3P_LN_FWD(NC)                                                                                                      \
     if (x_dtype == CM3P_BF16)                                                                                                \
-        layernorm_fwd_kernel<true, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps); \
+        layernorm_fwd_kernel<true, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps, reverse); \
     else                                                                                                                     \
-        layernorm_fwd_kernel<false, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps);
+        layernorm_fwd_kernel<false, NC><<<ln_grid(rows), 256, 0, s>>>(x, weight, y_f32, (uint16_t*)y_bf16, mean, rstd, rows, H, eps, reverse);
     CM3P_NC_SWITCH(H, CM3P_LN_FWD)
 #undef CM3P_LN_FWD
     CM3P_LAUNCH_CHECK();
