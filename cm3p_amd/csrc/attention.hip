@@ -28,6 +28,16 @@
 
 namespace {
 
+// a * c + b * s with a FIXED rounding sequence: the product b * s is rounded on its own (the empty asm keeps the compiler from folding it
+// into the addition), then one fma.  Left to the compiler, `a * c + b * s` becomes fma(a, c, b * s) in one template instance and
+// fma(b, s, a * c) in another (r04: the masked and the unmasked instance of the dQ sweep then disagreed in the last bit of two
+// elements out of 10^5, which is what the packed-equals-padded test compares).
+__device__ __forceinline__ float rot_fma(float a, float c, float b, float s) {
+    float t = b * s;
+    asm volatile("" : "+v"(t));
+    return __builtin_fmaf(a, c, t);
+}
+
 __device__ __forceinline__ float reg_max16(const f32x16& a) {  // 8 x v_max3_f32
     const float m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
     const float m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
@@ -425,8 +435,8 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a0 = dq[0][4 * g + r], b0 = dq[1][4 * g + r];
-                dq[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
-                dq[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
+                dq[0][4 * g + r] = rot_fma(a0, rcs[g][r], b0, rsn[g][r]);
+                dq[1][4 * g + r] = rot_fma(b0, rcs[g][r], -a0, rsn[g][r]);
             }
     }
     lds_only_barrier();  // every wave is done with the ring: its slots become the waves' transposition buffers
@@ -619,8 +629,8 @@ __device__ __forceinline__ void band_dkv_block(char* smem, int kblk, int head, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a0 = dk[0][4 * g + r], b0 = dk[1][4 * g + r];
-                dk[0][4 * g + r] = a0 * rcs[g][r] + b0 * rsn[g][r];
-                dk[1][4 * g + r] = b0 * rcs[g][r] - a0 * rsn[g][r];
+                dk[0][4 * g + r] = rot_fma(a0, rcs[g][r], b0, rsn[g][r]);
+                dk[1][4 * g + r] = rot_fma(b0, rcs[g][r], -a0, rsn[g][r]);
             }
     }
     lds_only_barrier();  // every wave is done with the ring: its slots become the waves' transposition buffers
