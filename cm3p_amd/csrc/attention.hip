@@ -802,9 +802,9 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
         return cm3p_launch_attn_bwd_global(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, scale, cos_tab, sin_tab, pos_batch_stride,
                                            vl.cu, vl.total, stages, pre, s);
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    // both stages in one call: the merged launch (CM3P_ATTN_BAND_MERGED=0: the two-kernel pair, bit-identical results)
+    // both stages in one call and CM3P_ATTN_BAND_MERGED=1: the merged launch (bit-identical results; measured no faster, r04: off by default)
     const char* env_m = getenv("CM3P_ATTN_BAND_MERGED");  // (read per call: one process can A/B)
-    const bool merged_ok = !(env_m && env_m[0] == '0');
+    const bool merged_ok = env_m && env_m[0] == '1';
     if (stages == (CM3P_ATTN_BWD_DQ | CM3P_ATTN_BWD_DKV) && merged_ok) {
         static const bool attr = [] {
             const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, false>),

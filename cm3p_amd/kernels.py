@@ -364,9 +364,11 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
 
 
 def band_merged_enabled() -> bool:
-    """Sliding-window backward: the dQ and dK / dV sweeps as neighbouring workgroups of ONE launch (default) or as the two-kernel pair
-    (CM3P_ATTN_BAND_MERGED=0); bit-identical results."""
-    return os.environ.get("CM3P_ATTN_BAND_MERGED", "1") != "0"
+    """Sliding-window backward: the two-kernel pair (default) or, with CM3P_ATTN_BAND_MERGED=1, the dQ and dK / dV sweeps as neighbouring
+    workgroups of ONE launch behind a delta pass; bit-identical results.  r04 A/B (one box each): stand-alone 0.626 vs 0.637 ms per C2
+    layer, 0.647 vs 0.646 at C4; inside the step the merged form is 0.5-1 ms SLOWER (C2 169.4 vs 168.7 ms, C4 215.4 vs 214.3): what the
+    shared rows save is what the delta pass costs.  Kept as the measured answer, off."""
+    return os.environ.get("CM3P_ATTN_BAND_MERGED", "0") == "1"
 
 
 def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int, scale: float, prescaled: bool = False):
