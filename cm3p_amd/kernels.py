@@ -351,7 +351,7 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
     # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip; sliding-window layers: the band kernels of attention.hip
-    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else _band_names(key_mask is not None)
     steps = ((ATTN_BWD_DQ, names[0], 1), (ATTN_BWD_DKV, names[1], 3))
     if window >= 0 and band_merged_enabled():
         # sliding-window layers: both sweeps in one launch behind the delta pass (csrc/attention.hip, attn_bwd_band_kernel)
@@ -361,6 +361,14 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
              window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, int(prescaled), stream(), tag=_attn_tag(name, window, prescaled),
              work=2.0 * products * B * nh * S * keys * 64)
     return dqkv
+
+
+def _band_names(masked: bool):
+    """rocprof rows of the sliding-window backward: resident workgroups that walk the blocks (default) or one workgroup per block
+    (CM3P_ATTN_BAND_PERSISTENT=0); bit-identical results."""
+    if os.environ.get("CM3P_ATTN_BAND_PERSISTENT", "1") != "0":
+        return ("attn_bwd_dq_pers_kernel<%s, " + ("true>" if masked else "false>"), "attn_bwd_dkv_pers_kernel<%s>")
+    return ("attn_bwd_dq_kernel<%s, " + ("true>" if masked else "false>"), "attn_bwd_dkv_kernel<%s>")
 
 
 def band_merged_enabled() -> bool:
@@ -389,7 +397,7 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
-    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else _band_names(False)
     steps = ((ATTN_BWD_DQ, names[0]), (ATTN_BWD_DKV, names[1]))
     if window >= 0 and band_merged_enabled():
         steps = ((ATTN_BWD_DQ | ATTN_BWD_DKV, "attn_bwd_band_kernel<%s, false>"),)

@@ -730,6 +730,7 @@ def test_sliding_window_backward_in_one_launch_equals_the_pair(K, monkeypatch, B
     tables = K.rope_table(torch.arange(S, device=DEV), inv_freq) if rope else None
     out, lse = K.attn_fwd(qkv, mask, B, S, nh, 64, 0.125, prescaled=prescaled)
     res = {}
+    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", mode)
         _lib_mod = __import__("cm3p_amd._lib", fromlist=["_lib"])
@@ -739,6 +740,14 @@ def test_sliding_window_backward_in_one_launch_equals_the_pair(K, monkeypatch, B
         assert any("attn_bwd_band_kernel" in t for t in tags) == (mode == "1"), sorted(tags)
     assert torch.isfinite(res["1"].float()).all()
     assert torch.equal(res["0"], res["1"])
+    # r04, the default: resident workgroups that walk the blocks with one LDS-DMA stream across them - the same arithmetic per block
+    monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", "0")
+    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "1")
+    _lib_mod.profile_begin()
+    pers = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, 64, 0.125, tables, False, prescaled=prescaled).clone()
+    assert any("attn_bwd_dq_pers_kernel" in t for t in _lib_mod.profile_end())
+    assert torch.equal(res["0"], pers)
+    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "0")
     if lens is not None:  # the packed form of the same batch
         idx = torch.nonzero(mask.flatten()).flatten()
         cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
@@ -750,6 +759,9 @@ def test_sliding_window_backward_in_one_launch_equals_the_pair(K, monkeypatch, B
             monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", mode)
             packed[mode] = K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, 64, 0.125, tables_p, prescaled=prescaled).clone()
         assert torch.equal(packed["0"], packed["1"])
+        monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", "0")
+        monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "1")
+        assert torch.equal(packed["0"], K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, 64, 0.125, tables_p, prescaled=prescaled))
 
 
 def test_gather_scatter_rows(K):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sliding-window backward: the two-kernel pair against the merged launch (CM3P_ATTN_BAND_MERGED), interleaved rounds in one process.
+"""Sliding-window backward, interleaved rounds in one process: one workgroup per block (the r03 pair), the merged launch
+(CM3P_ATTN_BAND_MERGED=1) and resident workgroups that walk the blocks (CM3P_ATTN_BAND_PERSISTENT, default since r04).
 
     python tools/band_bwd_ab.py [--batch 32 --seq 4096] [--rounds 5]
 """
@@ -29,16 +30,19 @@ def main():
     inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device="cuda", dtype=torch.float32) / 64))
     tables = K.rope_table(torch.arange(S, device="cuda"), inv_freq)
     out, lse = K.attn_fwd(qkv, None, B, S, nh, 64, 0.125, prescaled=True)
-    res = {"0": [], "1": []}
+    modes = {"pair": dict(CM3P_ATTN_BAND_PERSISTENT="0", CM3P_ATTN_BAND_MERGED="0"), "merged": dict(CM3P_ATTN_BAND_PERSISTENT="0", CM3P_ATTN_BAND_MERGED="1"),
+             "persistent": dict(CM3P_ATTN_BAND_PERSISTENT="1", CM3P_ATTN_BAND_MERGED="0")}
+    res = {m: [] for m in modes}
     outs = {}
+    run = lambda: K.attn_bwd(qkv, out, do, lse, None, B, S, nh, 64, 0.125, tables, False, prescaled=True)
     for _ in range(args.rounds):
-        for mode in ("0", "1"):
-            os.environ["CM3P_ATTN_BAND_MERGED"] = mode
-            res[mode].append(timeit(lambda: K.attn_bwd(qkv, out, do, lse, None, B, S, nh, 64, 0.125, tables, False, prescaled=True), args.iters))
-            outs[mode] = K.attn_bwd(qkv, out, do, lse, None, B, S, nh, 64, 0.125, tables, False, prescaled=True)
+        for m, env in modes.items():
+            os.environ.update(env)
+            res[m].append(timeit(run, args.iters))
+            outs[m] = run()
     torch.cuda.synchronize()
-    print(f"B={B} S={S}: pair {statistics.median(res['0']):.3f} ms (min {min(res['0']):.3f}) | one launch {statistics.median(res['1']):.3f} ms "
-          f"(min {min(res['1']):.3f}) | identical: {torch.equal(outs['0'], outs['1'])}", flush=True)
+    print(f"B={B} S={S}: " + " | ".join(f"{m} {statistics.median(v):.3f} ms (min {min(v):.3f})" for m, v in res.items())
+          + f" | identical: {all(torch.equal(outs['pair'], o) for o in outs.values())}", flush=True)
 
 
 if __name__ == "__main__":
