@@ -287,9 +287,7 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 constexpr int kDqStage = 2 * 8192 + 256;  // K image, V image, one validity dword per key
 constexpr int kDqSlots = 4;               // LDS-DMA ring: tile t+3 is requested while tile t is consumed
 
-// EXT_DELTA: delta[b, h, q] was written by attn_delta_kernel before this launch (the merged launch below); otherwise this sweep
-// computes it for its own rows from O and dO and publishes it for the dK / dV kernel that follows.
-template <bool PRE, bool MASK, bool EXT_DELTA>
+template <bool PRE, bool MASK>
 __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, int b, const uint16_t* __restrict__ qkv,
                                               const uint16_t* __restrict__ d_o, const uint16_t* __restrict__ o_rows,
                                               const float* __restrict__ lse, float* __restrict__ delta, uint16_t* __restrict__ dqkv,
@@ -355,9 +353,7 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
     // delta[q] = sum_d dO[q, d] O[q, d]: this lane holds half of its query's dO row already; the other half sits 32 lanes
     // away.  Written out for the dK/dV kernel, which runs after this one (no separate delta launch, one less pass over dO).
     float dlt = 0.f;
-    if constexpr (EXT_DELTA) {
-        dlt = delta[stat];
-    } else {
+    {
         const uint16_t* obase = o_rows + sv.row0 * ldo + head * 64;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -454,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int qblk, head, b;
     decode_block((Smax + 127) / 128, nh, qblk, head, b);
-    band_dq_block<PRE, MASK, false>(smem, qblk, head, b, qkv, d_o, o_rows, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin,
+    band_dq_block<PRE, MASK>(smem, qblk, head, b, qkv, d_o, o_rows, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin,
                                     pos_batch_stride, vl);
 }
 
@@ -655,444 +651,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     band_dkv_block<PRE>(smem, kblk, head, b, qkv, d_o, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin, pos_batch_stride, vl);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Sliding-window backward as ONE launch (r04).  The pair above reads q, k, v and dO twice (2.96 GB per C2 layer against 1.61 GB
-// algorithmic, r03 PMC) and both kernels already run at the rate their own traffic allows.  Here the dQ sweep and the dK / dV
-// sweep of the SAME 128 rows are neighbouring workgroups of one grid (logical id 2 n: queries [128 n, 128 n + 128) as the dQ
-// sweep; 2 n + 1: the same rows as keys), so they are resident on one XCD at the same time (decode_block) and whichever comes
-// second finds the K / V / Q / dO rows in that XCD's L2.  The sweeps themselves are the two kernels above, unchanged: same
-// products, same order, bit-identical results.  delta = rowsum(dO o O) can then no longer come from the dQ sweep (the dK / dV
-// sweep of a neighbouring workgroup would read it before it is written): attn_delta_kernel computes it first, in the dQ sweep's
-// summation order.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kBandLds = kDqSlots * kDqStage > kDkvSlots * kDkvStage ? kDqSlots * kDqStage : kDkvSlots * kDkvStage;
-
-template <bool PRE, bool MASK>
-__global__ __launch_bounds__(256, 2) void attn_bwd_band_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                               const float* __restrict__ lse, float* __restrict__ delta,
-                                                               uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
-                                                               int nh, int window, float scale, const float* __restrict__ rope_cos,
-                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int blk2, head, b;
-    decode_block(2 * ((Smax + 127) / 128), nh, blk2, head, b);
-    if (blk2 & 1)
-        band_dkv_block<PRE>(smem, blk2 >> 1, head, b, qkv, d_o, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin, pos_batch_stride, vl);
-    else
-        band_dq_block<PRE, MASK, true>(smem, blk2 >> 1, head, b, qkv, d_o, nullptr, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos,
-                                       rope_sin, pos_batch_stride, vl);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent sliding-window backward (r04).  What binds the two sweeps above is neither HBM nor the matrix pipe but the fixed costs of
-// a workgroup that lives for 4-5 tiles: the first DMA round trip, the row fragments' round trip, the store tail (r04 PMC: the merged
-// launch moved 30 % fewer bytes in the same time; MFMA + VALU are ~30 % of a workgroup's lifetime).  Here 2 workgroups per CU are
-// resident for the whole launch and walk 128-row blocks; the LDS-DMA ring is ONE stream over (block, tile) positions that never
-// drains - while block n is swept, the first tiles of block n + 1 are already landing - the row fragments of block n + 1 are
-// requested before block n's store tail, and the stores leave through a buffer of their own.  Per block the arithmetic is the
-// kernels' above: the same products in the same order, bit-identical results.
-// Block order: XCD x owns a contiguous range of logical blocks (the blocks of one (batch, head) are consecutive there) and its
-// workgroups take them round-robin, so that at any time an XCD works on neighbouring blocks and shares their tiles in its L2.
-// ---------------------------------------------------------------------------------------------------------------
-struct BandCtx {  // one 128-row block of one (batch, head), wave-uniform
-    int R0, S, head, b, t_lo, t_hi;
-    int64_t row0, stat0, pos0;
-};
-__device__ __forceinline__ bool band_ctx(BandCtx& c, int L, int nblk, int nh, int Smax, int window, int64_t pos_batch_stride, const VarLen& vl) {
-    const int blk = L % nblk, bh = L / nblk;
-    c.head = bh % nh;
-    c.b = bh / nh;
-    const SeqView sv(vl, c.b, c.head, Smax, nh);
-    c.S = sv.S;
-    c.row0 = sv.row0;
-    c.stat0 = sv.stat0;
-    c.pos0 = sv.pos0(c.b, pos_batch_stride);
-    c.R0 = blk * 128;
-    if (c.R0 >= c.S) return false;  // (unpadded batches: the block list is sized for the longest sequence)
-    const int R1 = min(c.S, c.R0 + 128) - 1;
-    const int lo = window < 0 ? 0 : max(0, c.R0 - window), hi = window < 0 ? c.S - 1 : min(c.S - 1, R1 + window);
-    c.t_lo = lo / 64;
-    c.t_hi = hi / 64;
-    return true;
-}
-// this workgroup's share of `total` logical blocks: [first, end) in steps of `step`
-__device__ __forceinline__ void band_my_blocks(int total, int& first, int& end, int& step) {
-    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    step = gridDim.x / 8;  // (the launch code makes the grid a multiple of 8)
-    const int q8 = total / 8, r8 = total % 8;
-    const int lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    first = lo + slot;
-    end = lo + q8 + (xcd < r8 ? 1 : 0);
-}
-constexpr int kPersEpi = 4 * 2304;  // store_rows32_h buffers of the four waves
-
-template <bool PRE, bool MASK>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_pers_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                                  const uint16_t* __restrict__ o_rows, const float* __restrict__ lse,
-                                                                  float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-                                                                  const uint8_t* __restrict__ kmask, int Smax, int nh, int window, float scale,
-                                                                  const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                                  int64_t pos_batch_stride, VarLen vl, int total) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = (Smax + 127) / 128;
-    int first, end, step;
-    band_my_blocks(total, first, end, step);
-    const int64_t ld = (int64_t)3 * nh * 64, ldo = (int64_t)nh * 64;
-    const int ldb = (int)ld * 2;
-    constexpr int ND = MASK ? 5 : 4;
-    const TileDma dma(wid, lane);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t m0_k = __builtin_amdgcn_readfirstlane(lds0 + 2048u * wid);
-    char* ebuf = smem + kDqSlots * kDqStage + 2304 * wid;
-    const float c = scale * kLog2e;
-
-    // ---- the tile stream: positions 0, 1, 2, ... over this workgroup's (block, tile) pairs; position p lives in ring slot p & 3
-    BandCtx sc;
-    int sL = first;
-    while (sL < end && !band_ctx(sc, sL, nblk, nh, Smax, window, pos_batch_stride, vl)) sL += step;
-    int st = sL < end ? sc.t_lo : 0;
-    int issued = 0, consumed = 0;
-    auto issue_one = [&]() {
-        if (sL >= end) return;
-        const char* kb = uniform_ptr(qkv + sc.row0 * ld + sc.head * 64 + nh * 64);
-        const uint32_t so = uniform_u32((uint32_t)(issued & (kDqSlots - 1)) * kDqStage);
-        const int Ss = (int)uniform_u32((uint32_t)sc.S), r0s = (int)uniform_u32((uint32_t)(st * 64));
-        dma.rows(m0_k + so, kb, ldb, r0s, Ss);
-        dma.rows(m0_k + so + 8192u, kb + nh * 128, ldb, r0s, Ss, CM3P_AUD_T1);
-        if constexpr (MASK) dma_ubyte64(uniform_u32(lds0 + so + 16384u), uniform_ptr(kmask + sc.row0), (uint32_t)min(r0s + lane, Ss - 1));
-        ++issued;
-        if (++st > sc.t_hi) {
-            sL += step;
-            while (sL < end && !band_ctx(sc, sL, nblk, nh, Smax, window, pos_batch_stride, vl)) sL += step;
-            if (sL < end) st = sc.t_lo;
-        }
-    };
-    issue_one();
-    issue_one();
-    issue_one();
-
-    BandCtx cc;
-    int cL = first;
-    while (cL < end && !band_ctx(cc, cL, nblk, nh, Smax, window, pos_batch_stride, vl)) cL += step;
-    // row fragments of the first block
-    bf16x8 qf[4], dof[4], of[4];
-    float lse_raw = 0.f;
-    auto load_rows = [&](const BandCtx& x) {
-        const int qr = min(x.R0 + wid * 32 + (lane & 31), x.S - 1);
-        const uint16_t* qb = qkv + x.row0 * ld + x.head * 64;
-        const uint16_t* dob = d_o + x.row0 * ldo + x.head * 64;
-        const uint16_t* ob = o_rows + x.row0 * ldo + x.head * 64;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            qf[s] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qr * ld + 16 * s + 8 * hh);
-            dof[s] = *reinterpret_cast<const bf16x8*>(dob + (int64_t)qr * ldo + 16 * s + 8 * hh);
-            of[s] = *reinterpret_cast<const bf16x8*>(ob + (int64_t)qr * ldo + 16 * s + 8 * hh);
-        }
-        lse_raw = lse[x.stat0 + qr];
-    };
-    if (cL < end) load_rows(cc);
-
-    while (cL < end) {
-        const int S = cc.S, q0 = cc.R0 + wid * 32;
-        const int wlo = window < 0 ? 0 : max(0, q0 - window), whi = window < 0 ? S - 1 : min(S - 1, q0 + 31 + window);
-        const bool wave_live = q0 < S;
-        const int qrow = q0 + (lane & 31);
-        const int qrow_c = qrow < S ? qrow : S - 1;
-        const int lo = window < 0 ? INT_MIN : qrow - window, hi = window < 0 ? S - 1 : min(qrow + window, S - 1);
-        const int64_t stat = cc.stat0 + qrow_c;
-        const float lse2 = PRE ? lse_raw * kLog2e : lse_raw / scale;
-        float dlt = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dlt += (float)of[s][j] * (float)dof[s][j];
-        dlt += __shfl_xor(dlt, 32, 64);
-        if (hh == 0 && qrow < S) delta[stat] = dlt;
-        f32x4 rcs[4], rsn[4];
-        if (rope_cos) {
-            const int64_t prow = cc.pos0 + qrow_c;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                rcs[g] = *reinterpret_cast<const f32x4*>(rope_cos + prow * 32 + 8 * g + 4 * hh);
-                rsn[g] = *reinterpret_cast<const f32x4*>(rope_sin + prow * 32 + 8 * g + 4 * hh);
-            }
-        }
-        f32x16 dq[2], lse_init, dlt_init;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dq[0][i] = dq[1][i] = 0.f;
-            lse_init[i] = -lse2;
-            dlt_init[i] = -dlt;
-        }
-        for (int t = cc.t_lo; t <= cc.t_hi; ++t) {
-            const char* stp = smem + (consumed & (kDqSlots - 1)) * kDqStage;
-            dma_wait_barrier(ND * (issued - consumed - 1));  // this position has landed in every wave; the previous one's slot is free
-            issue_one();
-            ++consumed;
-            const int key0 = t * 64;
-            if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
-                const uint32_t* mb = reinterpret_cast<const uint32_t*>(stp + 16384);
-                int all_valid = key0 + 63 < S;
-                if constexpr (MASK) all_valid = all_valid && __all(mb[lane] != 0u);
-                const bool unmasked = tile_unmasked(all_valid, key0, q0, window);
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    if (key0 + 32 * blk > whi || key0 + 32 * blk + 31 < wlo) continue;
-                    f32x16 sacc = mfma32(frag_R(stp, 32 * blk, 0, lane), qf[0], lse_init);
-                    f32x16 dp = mfma32(frag_R(stp + 8192, 32 * blk, 0, lane), dof[0], dlt_init);
-#pragma unroll
-                    for (int s = 1; s < 4; ++s) {
-                        sacc = mfma32(frag_R(stp, 32 * blk, s, lane), qf[s], sacc);
-                        dp = mfma32(frag_R(stp + 8192, 32 * blk, s, lane), dof[s], dp);
-                    }
-                    if (!unmasked) mask_scores_keyrows_d<MASK>(sacc, mb, blk, key0, lo, hi, hh);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
-                        sacc[i] = p * dp[i];
-                    }
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        const bf16x8 dsf = acc_to_frag(sacc, sp);
-                        dq[0] = mfma32(frag_T(stp, 32 * blk + 16 * sp, 0, lane), dsf, dq[0]);
-                        dq[1] = mfma32(frag_T(stp, 32 * blk + 16 * sp, 1, lane), dsf, dq[1]);
-                    }
-                }
-            }
-        }
-        // the next block's rows are requested before this block's store tail
-        const int64_t out_row0 = cc.row0 + q0;
-        const int head_c = cc.head, rows_left = S - q0;
-        cL += step;
-        while (cL < end && !band_ctx(cc, cL, nblk, nh, Smax, window, pos_batch_stride, vl)) cL += step;
-        if (cL < end) load_rows(cc);
-        if (rope_cos) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = dq[0][4 * g + r], b0 = dq[1][4 * g + r];
-                    dq[0][4 * g + r] = rot_fma(a0, rcs[g][r], b0, rsn[g][r]);
-                    dq[1][4 * g + r] = rot_fma(b0, rcs[g][r], -a0, rsn[g][r]);
-                }
-        }
-        store_rows32_h(ebuf, dq[0], dq[1], scale, dqkv + out_row0 * ld + head_c * 64, ld, rows_left, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
-}
-
-template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pers_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                   uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
-                                                                   int nh, int window, float scale, const float* __restrict__ rope_cos,
-                                                                   const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl,
-                                                                   int total) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = (Smax + 127) / 128;
-    int first, end, step;
-    band_my_blocks(total, first, end, step);
-    const int64_t ld = (int64_t)3 * nh * 64, ldo = (int64_t)nh * 64;
-    const int ND = wid == 0 ? 6 : 4;
-    const TileDma dma(wid, lane);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t m0_q = __builtin_amdgcn_readfirstlane(lds0 + 2048u * wid);
-    char* ebuf = smem + kDkvSlots * kDkvStage + 2304 * wid;
-    const float c = scale * kLog2e;
-    const float lse_mul = PRE ? -kLog2e : -1.0f / scale;
-
-    BandCtx sc;
-    int sL = first;
-    while (sL < end && !band_ctx(sc, sL, nblk, nh, Smax, window, pos_batch_stride, vl)) sL += step;
-    int st = sL < end ? sc.t_lo : 0;
-    int issued = 0, consumed = 0;
-    auto issue_one = [&]() {
-        if (sL >= end) return;
-        const char* qb = uniform_ptr(qkv + sc.row0 * ld + sc.head * 64);
-        const char* dob = uniform_ptr(d_o + sc.row0 * ldo + sc.head * 64);
-        const uint32_t so = uniform_u32((uint32_t)(issued & (kDkvSlots - 1)) * kDkvStage);
-        const int Ss = (int)uniform_u32((uint32_t)sc.S), r0s = (int)uniform_u32((uint32_t)(st * 64));
-        dma.rows(m0_q + so, qb, (int)ld * 2, r0s, Ss);
-        dma.rows(m0_q + so + 8192u, dob, (int)ldo * 2, r0s, Ss, CM3P_AUD_T1);
-        if (wid == 0) {
-            const uint32_t o4 = (uint32_t)(min(r0s + lane, Ss - 1) * 4);
-            dma_dword64(uniform_u32(lds0 + so + 16384u), uniform_ptr(lse + sc.stat0), o4);
-            dma_dword64(uniform_u32(lds0 + so + 16384u + 256u), uniform_ptr(delta + sc.stat0), o4, CM3P_AUD_S1);
-        }
-        ++issued;
-        if (++st > sc.t_hi) {
-            sL += step;
-            while (sL < end && !band_ctx(sc, sL, nblk, nh, Smax, window, pos_batch_stride, vl)) sL += step;
-            if (sL < end) st = sc.t_lo;
-        }
-    };
-    issue_one();
-    issue_one();
-    issue_one();
-
-    BandCtx cc;
-    int cL = first;
-    while (cL < end && !band_ctx(cc, cL, nblk, nh, Smax, window, pos_batch_stride, vl)) cL += step;
-    bf16x8 kf[4], vf[4];
-    bool key_ok = false;
-    auto load_rows = [&](const BandCtx& x) {
-        const int kr = x.R0 + wid * 32 + (lane & 31);
-        const int kr_c = min(kr, x.S - 1);
-        const uint16_t* kb = qkv + x.row0 * ld + x.head * 64 + nh * 64;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kf[s] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)kr_c * ld + 16 * s + 8 * hh);
-            vf[s] = *reinterpret_cast<const bf16x8*>(kb + nh * 64 + (int64_t)kr_c * ld + 16 * s + 8 * hh);
-        }
-        key_ok = kr < x.S && (kmask ? kmask[x.row0 + kr] != 0 : true);
-    };
-    if (cL < end) load_rows(cc);
-
-    while (cL < end) {
-        const int S = cc.S, k0 = cc.R0 + wid * 32;
-        const int wlo = window < 0 ? 0 : max(0, k0 - window), whi = window < 0 ? S - 1 : min(S - 1, k0 + 31 + window);
-        const bool wave_live = k0 < S;
-        const int krow = k0 + (lane & 31);
-        const int krow_c = krow < S ? krow : S - 1;
-        const bool keys_all_ok = __all(key_ok);
-        const bool key_ok_c = key_ok;
-        const int lo = window < 0 ? INT_MIN : krow - window, hi = window < 0 ? INT_MAX : krow + window;
-        f32x4 rcs[4], rsn[4];
-        if (rope_cos) {
-            const int64_t prow = cc.pos0 + krow_c;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                rcs[g] = *reinterpret_cast<const f32x4*>(rope_cos + prow * 32 + 8 * g + 4 * hh);
-                rsn[g] = *reinterpret_cast<const f32x4*>(rope_sin + prow * 32 + 8 * g + 4 * hh);
-            }
-        }
-        f32x16 dk[2], dv[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
-
-        for (int t = cc.t_lo; t <= cc.t_hi; ++t) {
-            char* stp = smem + (consumed & (kDkvSlots - 1)) * kDkvStage;
-            const int qt0 = t * 64;
-            dma_wait(ND * (issued - consumed - 1));  // this wave's part of the position has landed
-            if (wid == 0 && qt0 + lane >= S) {
-                reinterpret_cast<float*>(stp + 16384)[lane] = __builtin_huge_valf();
-                reinterpret_cast<float*>(stp + 16384 + 256)[lane] = 0.f;
-            }
-            lds_only_barrier();  // ... everyone's has; the slot of the previous position is free
-            issue_one();
-            ++consumed;
-            if (wave_live && qt0 <= whi && qt0 + 63 >= wlo) {
-                const float* nlse = reinterpret_cast<const float*>(stp + 16384);
-                const float* ndlt = nlse + 64;
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    if (qt0 + 32 * qb > whi || qt0 + 32 * qb + 31 < wlo) continue;
-                    f32x16 sacc, dp;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(nlse + 32 * qb + 8 * g + 4 * hh);
-                        const f32x4 d = *reinterpret_cast<const f32x4*>(ndlt + 32 * qb + 8 * g + 4 * hh);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            sacc[4 * g + r] = a[r] * lse_mul;
-                            dp[4 * g + r] = -d[r];
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        sacc = mfma32(frag_R(stp, 32 * qb, s, lane), kf[s], sacc);
-                        dp = mfma32(frag_R(stp + 8192, 32 * qb, s, lane), vf[s], dp);
-                    }
-                    const int qb0 = qt0 + 32 * qb;
-                    const bool plain = keys_all_ok && (window < 0 || (qb0 >= k0 + 31 - window && qb0 + 31 <= k0 + window));
-                    if (plain) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float p = __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c);
-                            sacc[i] = p;
-                            dp[i] = p * dp[i];
-                        }
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int i = 4 * g + r;
-                                const int q = qb0 + 8 * g + 4 * hh + r;
-                                const bool ok = key_ok_c & (q >= lo) & (q <= hi);
-                                const float p = ok ? __builtin_amdgcn_exp2f(PRE ? sacc[i] : sacc[i] * c) : 0.f;
-                                sacc[i] = p;
-                                dp[i] = p * dp[i];
-                            }
-                    }
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        const bf16x8 pf = acc_to_frag(sacc, sp);
-                        const bf16x8 dsf = acc_to_frag(dp, sp);
-                        const int r0 = 32 * qb + 16 * sp;
-                        dv[0] = mfma32(frag_T(stp + 8192, r0, 0, lane), pf, dv[0]);
-                        dv[1] = mfma32(frag_T(stp + 8192, r0, 1, lane), pf, dv[1]);
-                        dk[0] = mfma32(frag_T(stp, r0, 0, lane), dsf, dk[0]);
-                        dk[1] = mfma32(frag_T(stp, r0, 1, lane), dsf, dk[1]);
-                    }
-                }
-            }
-        }
-        const int64_t out_row0 = cc.row0 + k0;
-        const int head_c = cc.head, rows_left = S - k0;
-        cL += step;
-        while (cL < end && !band_ctx(cc, cL, nblk, nh, Smax, window, pos_batch_stride, vl)) cL += step;
-        if (cL < end) load_rows(cc);
-        if (rope_cos) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = dk[0][4 * g + r], b0 = dk[1][4 * g + r];
-                    dk[0][4 * g + r] = rot_fma(a0, rcs[g][r], b0, rsn[g][r]);
-                    dk[1][4 * g + r] = rot_fma(b0, rcs[g][r], -a0, rsn[g][r]);
-                }
-        }
-        uint16_t* dk0 = dqkv + out_row0 * ld + nh * 64 + head_c * 64;
-        store_rows32_h(ebuf, dk[0], dk[1], PRE ? 0.69314718055994531f : scale, dk0, ld, rows_left, lane);
-        store_rows32_h(ebuf, dv[0], dv[1], 1.0f, dk0 + nh * 64, ld, rows_left, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// delta[b, h, q] = sum_d dO[q, d] O[q, d] in the dQ sweep's order: lane (row, half) adds its 32 products (dims 16 s + 8 half + j, s and
-// then j ascending) and the two halves are added last.  One workgroup = 128 rows of one (batch, head), two threads per row.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o_rows, const uint16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int Smax, int nh, VarLen vl) {
-    int blk, head, b;
-    decode_block((Smax + 127) / 128, nh, blk, head, b);
-    const SeqView sv(vl, b, head, Smax, nh);
-    const int S = sv.S;
-    const int row = blk * 128 + (threadIdx.x >> 1), hh = threadIdx.x & 1;
-    if (blk * 128 >= S) return;
-    const int rc = row < S ? row : S - 1;
-    const int64_t ldo = (int64_t)nh * 64;
-    const uint16_t* po = o_rows + (sv.row0 + rc) * ldo + head * 64 + 8 * hh;
-    const uint16_t* pg = d_o + (sv.row0 + rc) * ldo + head * 64 + 8 * hh;
-    bf16x8 of[4], gf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        of[s] = *reinterpret_cast<const bf16x8*>(po + 16 * s);
-        gf[s] = *reinterpret_cast<const bf16x8*>(pg + 16 * s);
-    }
-    float dlt = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dlt += (float)of[s][j] * (float)gf[s][j];
-    dlt += __shfl_xor(dlt, 1, 64);
-    if (hh == 0 && row < S) delta[sv.stat0 + row] = dlt;
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // output_attentions: the probabilities themselves, [B, nh, S, S] fp32 - what the reference returns when a caller asks for
@@ -1183,70 +741,6 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
         return cm3p_launch_attn_bwd_global(qkv, out, dout, lse, delta, dqkv, key_mask, B, S, nh, scale, cos_tab, sin_tab, pos_batch_stride,
                                            vl.cu, vl.total, stages, pre, s);
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
-    // both stages in one call and CM3P_ATTN_BAND_MERGED=1: the merged launch (bit-identical results; measured no faster, r04: off by default)
-    const char* env_m = getenv("CM3P_ATTN_BAND_MERGED");  // (read per call: one process can A/B)
-    const bool merged_ok = env_m && env_m[0] == '1';
-    if (stages == (CM3P_ATTN_BWD_DQ | CM3P_ATTN_BWD_DKV) && merged_ok) {
-        static const bool attr = [] {
-            const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<true, false>),
-                                reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_band_kernel<false, false>)};
-            for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kBandLds);
-            return true;
-        }();
-        (void)attr;
-        attn_delta_kernel<<<grid, 256, 0, s>>>((const uint16_t*)out, (const uint16_t*)dout, delta, S, nh, vl);
-        if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
-        const dim3 grid2(2 * grid.x);
-#define CM3P_BAND_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        if (pre && key_mask) attn_bwd_band_kernel<true, true><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else if (pre) attn_bwd_band_kernel<true, false><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else if (key_mask) attn_bwd_band_kernel<false, true><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-        else attn_bwd_band_kernel<false, false><<<grid2, 256, kBandLds, s>>>(CM3P_BAND_ARGS);
-#undef CM3P_BAND_ARGS
-        return CM3P_OK;
-    }
-    // CM3P_ATTN_BAND_PERSISTENT=0: the one-workgroup-per-block kernels (bit-identical results)
-    const char* env_p = getenv("CM3P_ATTN_BAND_PERSISTENT");
-    if (!(env_p && env_p[0] == '0')) {
-        static int num_cu = 0;
-        if (num_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-            if (num_cu <= 0) num_cu = 256;
-        }
-        const int total = (int)grid.x;
-        int pg = 2 * num_cu;  // two resident workgroups per CU
-        if (pg > total) pg = total;
-        pg = (pg + 7) / 8 * 8;  // (band_my_blocks: a multiple of the 8 XCDs; surplus workgroups find no block)
-        static const bool attr_p = [] {
-            const void* fq[4] = {reinterpret_cast<const void*>(&attn_bwd_dq_pers_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_dq_pers_kernel<true, false>),
-                                 reinterpret_cast<const void*>(&attn_bwd_dq_pers_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_dq_pers_kernel<false, false>)};
-            for (const void* k : fq) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSlots * kDqStage + kPersEpi);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage + kPersEpi);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage + kPersEpi);
-            return true;
-        }();
-        (void)attr_p;
-        if (stages & CM3P_ATTN_BWD_DQ) {
-#define CM3P_DQP_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl, total
-            const size_t l = kDqSlots * kDqStage + kPersEpi;
-            if (pre && key_mask) attn_bwd_dq_pers_kernel<true, true><<<pg, 256, l, s>>>(CM3P_DQP_ARGS);
-            else if (pre) attn_bwd_dq_pers_kernel<true, false><<<pg, 256, l, s>>>(CM3P_DQP_ARGS);
-            else if (key_mask) attn_bwd_dq_pers_kernel<false, true><<<pg, 256, l, s>>>(CM3P_DQP_ARGS);
-            else attn_bwd_dq_pers_kernel<false, false><<<pg, 256, l, s>>>(CM3P_DQP_ARGS);
-#undef CM3P_DQP_ARGS
-            if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
-        }
-        if (stages & CM3P_ATTN_BWD_DKV) {
-#define CM3P_DKVP_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl, total
-            const size_t l = kDkvSlots * kDkvStage + kPersEpi;
-            if (pre) attn_bwd_dkv_pers_kernel<true><<<pg, 256, l, s>>>(CM3P_DKVP_ARGS);
-            else attn_bwd_dkv_pers_kernel<false><<<pg, 256, l, s>>>(CM3P_DKVP_ARGS);
-#undef CM3P_DKVP_ARGS
-        }
-        return CM3P_OK;
-    }
     if (stages & CM3P_ATTN_BWD_DQ) {
 #define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
         static const bool attr = [] {

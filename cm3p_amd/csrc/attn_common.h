@@ -176,32 +176,6 @@ __device__ __forceinline__ void store_rows32(char* buf, const f32x16& b0, const 
     asm volatile("" ::: "memory");
 }
 
-// The same through a 16-row buffer (16 x 144 bytes) in two passes, for kernels whose LDS has no room for 32 rows per wave.
-__device__ __forceinline__ void store_rows32_h(char* buf, const f32x16& b0, const f32x16& b1, float mul, uint16_t* dst_row0, int64_t ld_elems,
-                                               int nrows_valid, int lane) {
-    const int l31 = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if ((l31 >> 4) == half) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<uint2*>(buf + (l31 & 15) * 144 + (8 * g + 4 * hh) * 2) =
-                    uint2{pack_bf16x2(b0[4 * g] * mul, b0[4 * g + 1] * mul), pack_bf16x2(b0[4 * g + 2] * mul, b0[4 * g + 3] * mul)};
-                *reinterpret_cast<uint2*>(buf + (l31 & 15) * 144 + (32 + 8 * g + 4 * hh) * 2) =
-                    uint2{pack_bf16x2(b1[4 * g] * mul, b1[4 * g + 1] * mul), pack_bf16x2(b1[4 * g + 2] * mul, b1[4 * g + 3] * mul)};
-            }
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (lane >> 3) + 8 * i;
-            const uint4 v = *reinterpret_cast<const uint4*>(buf + row * 144 + (lane & 7) * 16);
-            if (16 * half + row < nrows_valid) gstore16<(CM3P_NT & 4) != 0>(dst_row0 + (16 * half + row) * ld_elems + (lane & 7) * 8, v);
-        }
-        asm volatile("" ::: "memory");
-    }
-}
-
 // ---- LDS-DMA staging of 64-row tiles by a four-wave workgroup (the sliding-window kernels of attention.hip) ---------------------
 // A [*, 64] bf16 matrix tile (64 rows x 128 bytes) goes to LDS as the swizzled image off_R / off_T read: wave w brings rows
 // 16 w .. 16 w + 15 as two 1-KiB pieces (global_load_lds_dwordx4: lane l's 16 bytes land at piece + 16 l = row l >> 3, chunk slot
@@ -231,14 +205,6 @@ struct TileDma {
                      : "memory", "m0");
     }
 };
-// a pointer / an LDS address that IS the same in every lane, made provably so for an "s" asm operand
-__device__ __forceinline__ const char* uniform_ptr(const void* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
 // 64 consecutive floats / bytes (one per lane, index clamped by the caller) -> 64 dwords at LDS address m0v (bytes zero-extended)
 __device__ __forceinline__ void dma_dword64(uint32_t m0v, const void* base, uint32_t byte_off, int audit_id = CM3P_AUD_S0) {
     CM3P_AUDIT(audit_id, static_cast<const char*>(base) + byte_off, 4);

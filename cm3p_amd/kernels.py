@@ -351,32 +351,12 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Opti
     keys = S if window < 0 else min(S, 2 * window + 1)
     cos, sin = rope if rope is not None else (None, None)
     # global layers: the hand-scheduled kernels of csrc/attention_bwd.hip; sliding-window layers: the band kernels of attention.hip
-    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else _band_names(key_mask is not None)
-    steps = ((ATTN_BWD_DQ, names[0], 1), (ATTN_BWD_DKV, names[1], 3))
-    if window >= 0 and band_merged_enabled():
-        # sliding-window layers: both sweeps in one launch behind the delta pass (csrc/attention.hip, attn_bwd_band_kernel)
-        steps = ((ATTN_BWD_DQ | ATTN_BWD_DKV, "attn_bwd_band_kernel<%s, " + ("true>" if key_mask is not None else "false>"), 4),)
-    for stage, name, products in steps:
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    for stage, name, products in ((ATTN_BWD_DQ, names[0], 1), (ATTN_BWD_DKV, names[1], 3)):
         call("cm3p_attn_bwd", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(key_mask, torch.uint8), B, S, nh,
              window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), S if per_batch else 0, stage, int(prescaled), stream(), tag=_attn_tag(name, window, prescaled),
              work=2.0 * products * B * nh * S * keys * 64)
     return dqkv
-
-
-def _band_names(masked: bool):
-    """rocprof rows of the sliding-window backward: resident workgroups that walk the blocks (default) or one workgroup per block
-    (CM3P_ATTN_BAND_PERSISTENT=0); bit-identical results."""
-    if os.environ.get("CM3P_ATTN_BAND_PERSISTENT", "1") != "0":
-        return ("attn_bwd_dq_pers_kernel<%s, " + ("true>" if masked else "false>"), "attn_bwd_dkv_pers_kernel<%s>")
-    return ("attn_bwd_dq_kernel<%s, " + ("true>" if masked else "false>"), "attn_bwd_dkv_kernel<%s>")
-
-
-def band_merged_enabled() -> bool:
-    """Sliding-window backward: the two-kernel pair (default) or, with CM3P_ATTN_BAND_MERGED=1, the dQ and dK / dV sweeps as neighbouring
-    workgroups of ONE launch behind a delta pass; bit-identical results.  r04 A/B (one box each): stand-alone 0.626 vs 0.637 ms per C2
-    layer, 0.647 vs 0.646 at C4; inside the step the merged form is 0.5-1 ms SLOWER (C2 169.4 vs 168.7 ms, C4 215.4 vs 214.3): what the
-    shared rows save is what the delta pass costs.  Kept as the measured answer, off."""
-    return os.environ.get("CM3P_ATTN_BAND_MERGED", "0") == "1"
 
 
 def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window: int, scale: float, prescaled: bool = False):
@@ -397,11 +377,8 @@ def attn_bwd_varlen(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, cu: Ten
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     cos, sin = rope if rope is not None else (None, None)
-    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else _band_names(False)
-    steps = ((ATTN_BWD_DQ, names[0]), (ATTN_BWD_DKV, names[1]))
-    if window >= 0 and band_merged_enabled():
-        steps = ((ATTN_BWD_DQ | ATTN_BWD_DKV, "attn_bwd_band_kernel<%s, false>"),)
-    for stage, name in steps:
+    names = ("attn_bwd_dq3_kernel", "attn_bwd_dkv3_kernel<%s>") if window < 0 else ("attn_bwd_dq_kernel<%s>", "attn_bwd_dkv_kernel<%s>")
+    for stage, name in ((ATTN_BWD_DQ, names[0]), (ATTN_BWD_DKV, names[1])):
         call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), B, max_s,
              qkv.shape[0], nh, window, scale, ptr(cos, torch.float32), ptr(sin, torch.float32), stage, int(prescaled), stream(), tag=_attn_tag(name, window, prescaled, True))
     return dqkv

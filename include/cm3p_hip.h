@@ -202,10 +202,6 @@ int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, 
  * stages: which of the backward's kernels to launch - CM3P_ATTN_BWD_DQ (the dq third of dqkv, and delta),
  * CM3P_ATTN_BWD_DKV (the dk and dv thirds; reads the delta a DQ stage wrote earlier on the same stream), or both (3).
  * Callers that time kernels one by one issue the stages as two calls; the results are identical.
- * Sliding-window layers (window >= 0) with stages = 3 and CM3P_ATTN_BAND_MERGED=1 in the environment: ONE launch in which the dq sweep
- * and the dk / dv sweep of the same 128 rows are neighbouring workgroups (they share the rows through the XCD's L2 instead of reading
- * q, k, v and dO twice from HBM), behind a small kernel that writes delta in the dq sweep's summation order - bit-identical to the
- * two-stage form, and measured no faster (r04), hence opt-in.
  * dqkv's q third is the gradient w.r.t. the UN-scaled rotated q in both q_prescaled modes (the chain rule through q_scale is
  * applied inside), i.e. what the Wqkv GEMM's backward expects. */
 #define CM3P_ATTN_BWD_DQ 1

@@ -712,58 +712,6 @@ def test_attention_varlen_equals_padded_on_valid_rows(K, window):
     assert torch.equal(dqkv_p, dqkv.reshape(B * S, 3, nh, 64)[idx])
 
 
-@pytest.mark.parametrize("B,S,lens,prescaled,rope", [(2, 1000, None, True, True), (3, 515, [515, 130, 1], False, True), (1, 4096, None, True, False),
-                                                      (2, 65, [65, 64], True, False), (1, 8200, [7001], True, True)])
-def test_sliding_window_backward_in_one_launch_equals_the_pair(K, monkeypatch, B, S, lens, prescaled, rope):
-    """r04: the dQ sweep and the dK / dV sweep of the same 128 rows as neighbouring workgroups of ONE launch (they share q, k, v, dO
-    through the XCD's L2), behind attn_delta_kernel, against the two-kernel pair (CM3P_ATTN_BAND_MERGED=0): the same products in the
-    same order, delta summed in the same order - every bit of dq, dk, dv must agree (dead rows, key padding, sequences that end inside
-    a tile, both q modes, with and without the RoPE epilogue), and on packed sequences too."""
-    nh = 2
-    g = torch.Generator(device=DEV).manual_seed(S + B)
-    qkv = (torch.randn(B, S, 3, nh, 64, device=DEV, generator=g) * 0.7).bfloat16()
-    do = (torch.randn(B * S, nh * 64, device=DEV, generator=g) * 0.3).bfloat16()
-    mask = None
-    if lens is not None:
-        mask = (torch.arange(S, device=DEV)[None] < torch.tensor(lens, device=DEV)[:, None]).to(torch.uint8).contiguous()
-    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=DEV, dtype=torch.float32) / 64))
-    tables = K.rope_table(torch.arange(S, device=DEV), inv_freq) if rope else None
-    out, lse = K.attn_fwd(qkv, mask, B, S, nh, 64, 0.125, prescaled=prescaled)
-    res = {}
-    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", mode)
-        _lib_mod = __import__("cm3p_amd._lib", fromlist=["_lib"])
-        _lib_mod.profile_begin()
-        res[mode] = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, 64, 0.125, tables, False, prescaled=prescaled).clone()
-        tags = _lib_mod.profile_end()
-        assert any("attn_bwd_band_kernel" in t for t in tags) == (mode == "1"), sorted(tags)
-    assert torch.isfinite(res["1"].float()).all()
-    assert torch.equal(res["0"], res["1"])
-    # r04, the default: resident workgroups that walk the blocks with one LDS-DMA stream across them - the same arithmetic per block
-    monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", "0")
-    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "1")
-    _lib_mod.profile_begin()
-    pers = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, 64, 0.125, tables, False, prescaled=prescaled).clone()
-    assert any("attn_bwd_dq_pers_kernel" in t for t in _lib_mod.profile_end())
-    assert torch.equal(res["0"], pers)
-    monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "0")
-    if lens is not None:  # the packed form of the same batch
-        idx = torch.nonzero(mask.flatten()).flatten()
-        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
-        qkv_p, do_p = qkv.reshape(B * S, 3, nh, 64)[idx].contiguous(), do[idx].contiguous()
-        tables_p = K.rope_table((idx % S).contiguous(), inv_freq) if rope else None
-        out_p, lse_p = K.attn_fwd_varlen(qkv_p, cu, B, max(lens), nh, 64, 0.125, prescaled=prescaled)
-        packed = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", mode)
-            packed[mode] = K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, 64, 0.125, tables_p, prescaled=prescaled).clone()
-        assert torch.equal(packed["0"], packed["1"])
-        monkeypatch.setenv("CM3P_ATTN_BAND_MERGED", "0")
-        monkeypatch.setenv("CM3P_ATTN_BAND_PERSISTENT", "1")
-        assert torch.equal(packed["0"], K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, 64, 0.125, tables_p, prescaled=prescaled))
-
-
 def test_gather_scatter_rows(K):
     x = torch.randn(37, 64, device=DEV)
     idx = torch.tensor([5, 0, 36, 7, 8], device=DEV)
