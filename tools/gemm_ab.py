@@ -52,22 +52,30 @@ def main():
     if "check" in args.what:
         bad = 0
         for (M, N, Kd) in ((4096, 4096, 4096), (131072, 2304, 768), (65536, 768, 1152), (65536 + 64, 1152, 768), (8192 + 8, 2304 + 64, 64),
-                           (12800, 768, 192), (256 * 30, 256 * 7, 128)):
+                           (12800, 768, 192), (256 * 30, 256 * 7, 128), (8208, 2320, 96), (70000, 784, 768)):
             a, w = uni(M, Kd), uni(N, Kd)
             r = torch.randn(M, N, device=DEV, generator=g)
+            S = 4096 if M % 4096 == 0 else M
+            cos, sin = torch.randn(S, 32, device=DEV, generator=g), torch.randn(S, 32, device=DEV, generator=g)
+            rope_ok = N % 256 == 0 and Kd % 64 == 0
             outs = {}
-            for name in ("256", "8p"):
+            for name in IMPLS:
                 impl(name)
-                outs[name] = (K.linear_fwd(a, w), K.linear_fwd(a, w, resid=r), K.gemm(a, w, M, N, Kd, True, True, K.EPI_F32))
+                outs[name] = [K.linear_fwd(a, w), K.linear_fwd(a, w, resid=r), K.gemm(a, w, M, N, Kd, True, True, K.EPI_F32)]
+                if rope_ok:
+                    outs[name].append(K.qkv_linear_rope(a, w, cos, sin, S, False, 0.18))
             torch.cuda.synchronize()
-            for i, kind in enumerate(("bf16", "f32+resid", "f32")):
-                x, y = outs["256"][i].float(), outs["8p"][i].float()
-                d = (x - y).abs().max().item()
-                ref = (a[:64].float() @ w.float().T) + (r[:64] if i == 1 else 0)
-                dr = (y[:64] - ref).abs().max().item()
-                ok = d == 0.0
-                bad += (not ok)
-                print(f"check [{M}x{N}x{Kd}] {kind:9s} max|256-8p| = {d:.3e}  max|8p-torch| (64 rows) = {dr:.3e}  {'OK' if ok else 'MISMATCH'}", flush=True)
+            for other in IMPLS[1:]:
+                for i, kind in enumerate(("bf16", "f32+resid", "f32", "bf16+rope")[:len(outs[IMPLS[0]])]):
+                    x, y = outs[IMPLS[0]][i].float(), outs[other][i].float()
+                    d = (x - y).abs().max().item()
+                    dr = 0.0
+                    if i < 3:
+                        ref = (a[:64].float() @ w.float().T) + (r[:64] if i == 1 else 0)
+                        dr = (y[:64] - ref).abs().max().item()
+                    ok = d == 0.0 and bool(torch.isfinite(y).all())
+                    bad += (not ok)
+                    print(f"check [{M}x{N}x{Kd}] {kind:9s} max|{IMPLS[0]}-{other}| = {d:.3e}  max|{other}-torch| (64 rows) = {dr:.3e}  {'OK' if ok else 'MISMATCH'}", flush=True)
         if bad:
             print(f"{bad} MISMATCHES")
             sys.exit(1)
