@@ -24,6 +24,10 @@
 
 #include "common.h"
 
+#ifndef CM3P_G4W_SCHED
+#define CM3P_G4W_SCHED 0  // how a k-step's fragment reads and MFMAs are placed (one-call A/B, tools/ubench/g4w_variants.sh)
+#endif
+
 namespace {
 
 constexpr int kStage4 = 8192 + 16384;  // A image + B image of one k-step
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const uint16_t* __restri
             }
             __builtin_amdgcn_s_barrier();                     // ... everybody's have, and everybody is done reading position pos - 1
             stream_issue();                                   // position pos + 2 -> the slot of position pos - 1
+#if CM3P_G4W_SCHED == 0
             bf16x8 fa[8], fb[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8*>(st + fb_off + nt * 1024);
@@ -263,6 +268,41 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const uint16_t* __restri
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+#elif CM3P_G4W_SCHED == 1  // the compiler places reads and MFMAs (its own counted lgkmcnt waits)
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8*>(st + fb_off + nt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(st + fa_off + mt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+#else  // two halves: the A fragments of rows 64 .. 127 are requested before the MFMAs of rows 0 .. 63 are issued
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = *reinterpret_cast<const bf16x8*>(st + fb_off + nt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(st + fa_off + mt * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 4; mt < 8; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(st + fa_off + mt * 1024);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 4; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // the wave's own B region of the slot it has just read (see the header): its next writer is this wave's DMA of position pos + 2
         epilogue(m0, n0, smem + ((pos - 1) % 3) * kStage4 + 8192 + wid * 4096);

@@ -57,7 +57,7 @@ def main():
             r = torch.randn(M, N, device=DEV, generator=g)
             S = 4096 if M % 4096 == 0 else M
             cos, sin = torch.randn(S, 32, device=DEV, generator=g), torch.randn(S, 32, device=DEV, generator=g)
-            rope_ok = N % 256 == 0 and Kd % 64 == 0
+            rope_ok = N % 768 == 0 and N >= 2304 and Kd % 64 == 0
             outs = {}
             for name in IMPLS:
                 impl(name)
