@@ -284,27 +284,9 @@ static inline bool use_small_only() {
     return e && e[0] == '1';
 }
 
-// gemm4w.hip: 128 x 256 tiles, four waves, two workgroups per CU (k-contiguous operands, no k-split); CM3P_ERR_INVALID = not covered
-int cm3p_gemm4w_dispatch(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                         int64_t ldc, int epi, hipStream_t s, RopeArgs rope);
-
-// Which big-shape kernel takes a shape whose operands are both k-contiguous and whose contraction is not split (read per call):
-// CM3P_GEMM_IMPL=4w every such shape, =8p none; default: the shapes it measured faster on (r04).
-static inline bool use_4w(int epi, int64_t N, int64_t K) {
-    const char* e = getenv("CM3P_GEMM_IMPL");
-    if (e && e[0] == '4') return true;
-    if (e && e[0] != 0) return false;
-    (void)epi; (void)N; (void)K;
-    return false;
-}
-
 static inline int big_gemm(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                            int64_t ldc, int a_kc, int b_kc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s,
                            RopeArgs rope) {
-    if (a_kc && b_kc && splits == 1 && use_4w(epi, N, K)) {
-        const int rc = cm3p_gemm4w_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, epi, s, rope);
-        if (rc != CM3P_ERR_INVALID) return rc;
-    }
     if (use_8p()) {
         const int rc = cm3p_gemm8p_dispatch(A, B, C, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, splits, kchunk, c_split_stride, s, rope);
         if (rc != CM3P_ERR_INVALID) return rc;
@@ -324,7 +306,6 @@ int cm3p_audit_set_gemm8p(void*);
 int cm3p_audit_set_gemm256(void*);
 int cm3p_audit_set_attention(void*);
 int cm3p_audit_set_attention_bwd_fused(void*);
-int cm3p_audit_set_gemm4w(void*);
 #endif
 
 extern "C" {
@@ -338,7 +319,6 @@ int cm3p_debug_set_dma_audit(void* buf) {
 #if CM3P_DMA_AUDIT
     int rc = cm3p_audit_set_gemm8p(buf);
     if (rc == CM3P_OK) rc = cm3p_audit_set_gemm256(buf);
-    if (rc == CM3P_OK) rc = cm3p_audit_set_gemm4w(buf);
     if (rc == CM3P_OK) rc = cm3p_audit_set_attention(buf);
     if (rc == CM3P_OK) rc = cm3p_audit_set_attention_bwd_fused(buf);
     return rc;
