@@ -42,6 +42,7 @@ SIGNATURES = {
     "cm3p_debug_set_dma_audit": [_P],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],
     "cm3p_cast_f32_bf16_t": [_P, _P, _P, _L, _L, _P],
+    "cm3p_cast_f32_bf16_t_multi": [_P, _I, _L, _P],
     "cm3p_add_f32": [_P, _P, _I, _P, _P, _L, _P],
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],

@@ -71,6 +71,51 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_t_kernel(const float* __res
     }
 }
 
+// The same for MANY matrices in one launch (a tower's Wqkv / Wo / Wi / Wo2 of every layer at the start of a training forward: r03 cast
+// each of them in a launch of its own, 8 us apiece for a few us of work).  table[6 i ..]: source, bf16 copy, transposed copy (device
+// addresses), rows, cols, first block of matrix i; block b belongs to the last matrix whose first block is <= b.
+__global__ __launch_bounds__(256) void cast_f32_bf16_t_multi_kernel(const int64_t* __restrict__ table, int n) {
+    __shared__ uint16_t tile[64][66];
+    int lo = 0, hi = n - 1;  // (wave-uniform bisection over at most a few hundred entries)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[6 * mid + 5] <= (int64_t)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const float* x = reinterpret_cast<const float*>(table[6 * lo]);
+    uint16_t* y = reinterpret_cast<uint16_t*>(table[6 * lo + 1]);
+    uint16_t* yt = reinterpret_cast<uint16_t*>(table[6 * lo + 2]);
+    const int rows = (int)table[6 * lo + 3], cols = (int)table[6 * lo + 4];
+    const int blk = (int)((int64_t)blockIdx.x - table[6 * lo + 5]);
+    const int tiles_c = (cols + 63) / 64;
+    const int r0 = (blk / tiles_c) * 64, c0 = (blk % tiles_c) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 16 + (tid >> 4), c = (tid & 15) * 4;
+        if (r0 + r < rows && c0 + c < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + r) * cols + c0 + c);
+            const uint32_t lo2 = pack_bf16x2(v.x, v.y), hi2 = pack_bf16x2(v.z, v.w);
+            *reinterpret_cast<uint2*>(y + (int64_t)(r0 + r) * cols + c0 + c) = uint2{lo2, hi2};
+            tile[r][c] = (uint16_t)lo2;
+            tile[r][c + 1] = (uint16_t)(lo2 >> 16);
+            tile[r][c + 2] = (uint16_t)hi2;
+            tile[r][c + 3] = (uint16_t)(hi2 >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = it * 32 + (tid >> 3), r = (tid & 7) * 8;
+        if (c0 + c < cols && r0 + r < rows) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[r + 2 * k][c] | ((uint32_t)tile[r + 2 * k + 1][c] << 16);
+            *reinterpret_cast<uint4*>(yt + (int64_t)(c0 + c) * rows + r0 + r) = uint4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
 template <bool B_BF16>
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const void* __restrict__ b, float* y32,
                                                       uint16_t* __restrict__ y16, int64_t n4) {
@@ -297,6 +342,13 @@ int cm3p_cast_f32_bf16_t(const float* x, void* y, void* y_t, int64_t rows, int64
     CM3P_REQUIRE(cm3p_aligned16(x) && cm3p_aligned16(y) && cm3p_aligned16(y_t));
     const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((cols + 63) / 64);
     cast_f32_bf16_t_kernel<<<tiles_r * tiles_c, 256, 0, static_cast<hipStream_t>(stream)>>>(x, (uint16_t*)y, (uint16_t*)y_t, (int)rows, (int)cols, tiles_c);
+    CM3P_LAUNCH_CHECK();
+    return CM3P_OK;
+}
+
+int cm3p_cast_f32_bf16_t_multi(const int64_t* table, int n, int64_t total_blocks, void* stream) {
+    CM3P_REQUIRE(table && n > 0 && total_blocks > 0 && total_blocks < (int64_t(1) << 31));
+    cast_f32_bf16_t_multi_kernel<<<(int)total_blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(table, n);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

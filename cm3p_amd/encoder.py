@@ -145,7 +145,7 @@ class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
     __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint",
-                 "handoff", "attn_out")
+                 "handoff", "attn_out", "wcast")
 
 
 def _hand_upstream(geo: _Geometry, gx32: Tensor, gx16: Optional[Tensor]) -> None:
@@ -214,7 +214,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         # forward-only and a shape of the ring kernel: the Wi GEMM stores gelu(h) * g itself (CM3P_GEGLU_FUSED=0: the two-kernel path)
         fuse_geglu = (not geo.save) and Wi.dim() == 2 and K.gemm_geglu_supported(x.shape[0], Wi.shape[0] // 2, Wi.shape[1]) \
             and os.environ.get("CM3P_GEGLU_FUSED", "1") != "0"
-        pairs = [_bf16_weight_pair(w, geo.save) if not (fuse_geglu and w is Wi) else (None, None) for w in (Wqkv, Wo, Wi, Wo2)]
+        # (training: the casts of every layer were made in one launch at the top of the stack, _run_stack)
+        pre = geo.wcast if geo.save and geo.wcast is not None else {}
+        pairs = [pre.get(id(w)) or _bf16_weight_pair(w, geo.save) if not (fuse_geglu and w is Wi) else (None, None) for w in (Wqkv, Wo, Wi, Wo2)]
         wb = (w_an, pairs[0][0], pairs[1][0], w_mn, pairs[2][0], pairs[3][0], _bf16_weight_cached(Wi, True) if fuse_geglu else None)
         x_out, acts = _layer_forward(geo, i, x, wb, geo.save)
         if geo.save:
@@ -528,6 +530,13 @@ class CM3PEncoder(nn.Module):
                                                 or any(w.requires_grad for ws in weights for w in ws))
         if geo.save and _eval_weights:
             invalidate_weight_cache()  # a backward will follow, so an optimizer will: no copy made before this step may outlive it
+        geo.wcast = None
+        if geo.save and os.environ.get("CM3P_CAST_BATCHED", "1") != "0":
+            # bf16 copies + transposes of every projection weight of the stack in ONE launch (r03: 4 launches per layer)
+            elig = [w for ws in weights for w in ws
+                    if w.dim() == 2 and w.dtype == torch.float32 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0 and w.is_contiguous()]
+            if elig:
+                geo.wcast = {id(w): pair for w, pair in zip(elig, K.cast_bf16_with_transpose_many([w.detach() for w in elig]))}
         geo.handoff = None
         geo.attn_out = [] if output_attentions else None
         # output_hidden_states: the stack's input and every layer's output (TF:...modeling_modernbert.py:457-470), detached

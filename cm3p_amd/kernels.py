@@ -238,6 +238,28 @@ def cast_bf16_with_transpose(x: Tensor):
     return y, yt
 
 
+def cast_bf16_with_transpose_many(ws: list) -> list:
+    """[fp32 2-D weights, extents multiples of 8] -> [(bf16 copy, bf16 transpose)] in ONE launch (cm3p_cast_f32_bf16_t_multi): the values
+    of cast_bf16_with_transpose per matrix.  One bf16 allocation holds all copies; the address table travels with one small H2D copy."""
+    if not ws:
+        return []
+    dev = ws[0].device
+    numel = sum(w.numel() for w in ws)
+    store = torch.empty((2 * numel,), dtype=torch.bfloat16, device=dev)
+    base, out, table, off, blocks = store.data_ptr(), [], [], 0, 0
+    for w in ws:
+        rows, cols = w.shape
+        y = store[off:off + rows * cols].view(rows, cols)
+        yt = store[off + rows * cols:off + 2 * rows * cols].view(cols, rows)
+        table += [w.data_ptr(), base + 2 * off, base + 2 * (off + rows * cols), rows, cols, blocks]
+        out.append((y, yt))
+        off += 2 * rows * cols
+        blocks += (-(-rows // 64)) * (-(-cols // 64))
+    tab = torch.tensor(table, dtype=torch.int64).to(dev, non_blocking=True)
+    call("cm3p_cast_f32_bf16_t_multi", ptr(tab, torch.int64), len(ws), blocks, stream(), work=8.0 * numel)
+    return out
+
+
 def add_f32(a: Tensor, b: Tensor, want_bf16: bool = False, inplace: bool = True):
     y32 = a if inplace else torch.empty_like(a)
     y16 = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device) if want_bf16 else None

@@ -154,6 +154,11 @@ int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
  * GEMM dx = dy W then reads W^T with the contraction index contiguous (a_kc = b_kc = 1), the faster operand form of the 256 x 256
  * kernel - nn.Linear's autograd does the same by handing the transposed view to the BLAS.  rows, cols multiples of 8. */
 int cm3p_cast_f32_bf16_t(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream);
+/* The same for n matrices in ONE launch (all the projection weights of a tower at the start of a training forward).  table: n rows of
+ * six int64 on the device - source (fp32 [rows, cols]), bf16 copy, transposed bf16 copy [cols, rows] (device addresses, 16-byte
+ * aligned), rows, cols (multiples of 8), index of the matrix's first 64 x 64 block - with first-block indices ascending from 0;
+ * total_blocks = the sum of ceil(rows / 64) * ceil(cols / 64).  The table is the caller's (it must outlive the launch). */
+int cm3p_cast_f32_bf16_t_multi(const int64_t* table, int n, int64_t total_blocks, void* stream);
 /* y_f32 (and y_bf16 if not NULL) = a_f32 + b (b fp32 or bf16); n % 4 == 0.  Residual-gradient join for layer 0,
  * whose attn_norm is nn.Identity (TF:...modeling_modernbert.py:309-310). */
 int cm3p_add_f32(const float* a, const void* b, int b_dtype, float* y_f32, void* y_bf16, int64_t n, void* stream);

@@ -732,6 +732,19 @@ def test_cast_with_transpose(K, rows, cols):
     assert torch.equal(y, w.to(torch.bfloat16)) and torch.equal(yt, w.to(torch.bfloat16).t().contiguous())
 
 
+def test_cast_with_transpose_of_many_matrices_in_one_launch(K):
+    """cm3p_cast_f32_bf16_t_multi: every matrix gets exactly what the one-matrix kernel gives (edge tiles, one-tile matrices, a repeated
+    shape), and the copies do not overlap."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(2304, 768), (768, 768), (768, 1152), (72, 8), (200, 136), (2304, 768), (64, 64), (8, 520)]
+    ws = [torch.randn(r, c, generator=g).to(DEV) for r, c in shapes]
+    got = K.cast_bf16_with_transpose_many(ws)
+    assert len(got) == len(ws)
+    for w, (y, yt) in zip(ws, got):
+        assert torch.equal(y, w.to(torch.bfloat16)) and torch.equal(yt, w.to(torch.bfloat16).t().contiguous())
+    assert K.cast_bf16_with_transpose_many([]) == []
+
+
 @pytest.mark.parametrize("T,N,K_", [(65536, 768, 1152), (32768 + 64, 2304, 768), (512, 256, 128)])
 def test_dgrad_through_transposed_weight_equals_strided_dgrad(K, T, N, K_):
     """dx = dy W computed from W^T (contraction index contiguous in both operands) is bit-identical to the k-strided form:
