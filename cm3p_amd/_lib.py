@@ -48,6 +48,10 @@ SIGNATURES = {
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
     "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "cm3p_attn_probs": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "cm3p_attn_generic_supported": [_I],
+    "cm3p_attn_fwd_generic": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "cm3p_attn_bwd_generic": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "cm3p_rope_apply_generic": [_P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "cm3p_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _L, _I, _I, _P],
     "cm3p_geglu_fwd": [_P, _P, _L, _I, _P],
     "cm3p_gemm_geglu": [_P, _P, _P, _L, _L, _L, _P],

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_bwd.hip", "attention_bwd_fused.hip", "head.hip", "conv.hip", "muon.hip"]
+SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_bwd.hip", "attention_bwd_fused.hip", "attention_generic.hip", "head.hip", "conv.hip", "muon.hip"]
 LIB = os.path.join(CSRC, "libcm3p_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # hand-scheduled kernels: SLP-packing adjacent f32 multiplies into v_pk_mul_f32 costs register shuffles (v_mov / v_perm /

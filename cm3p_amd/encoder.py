@@ -33,8 +33,10 @@ Tensor = torch.Tensor
 def _check_supported(cfg):
     H, nh = cfg.hidden_size, cfg.num_attention_heads
     problems = []
-    if H % nh or H // nh != 64:
-        problems.append(f"head_dim must be 64 (hidden_size={H}, heads={nh})")
+    if H % nh or H // nh not in (16, 32, 64):
+        # 64: the MFMA kernels every default tower runs on; 16 / 32: csrc/attention_generic.hip (plain fp32 kernels, so that the
+        # reference's small test configurations run as well)
+        problems.append(f"head_dim must be 64 (or 16 / 32 on the generic kernels); hidden_size={H}, heads={nh}")
     if getattr(cfg, "hidden_activation", "gelu") != "gelu":
         problems.append("hidden_activation must be 'gelu'")
     for flag in ("norm_bias", "attention_bias", "mlp_bias"):
@@ -145,7 +147,7 @@ class _Geometry:
     """Static description of one forward call of the stack (no tensors that need grad)."""
 
     __slots__ = ("B", "S", "H", "I", "nh", "L", "eps", "windows", "key_mask", "rope", "per_batch_pos", "save", "cu", "max_s", "checkpoint",
-                 "handoff", "attn_out", "wcast")
+                 "handoff", "attn_out", "wcast", "hd")
 
 
 def _hand_upstream(geo: _Geometry, gx32: Tensor, gx16: Optional[Tensor]) -> None:
@@ -173,18 +175,25 @@ def _layer_forward(geo: _Geometry, i: int, x: Tensor, wb, want_stats: bool):
     """One encoder layer on [T, H] rows: -> (x_out, activations needed by its backward)."""
     w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = wb[:6]
     B, S, nh = geo.B, geo.S, geo.nh
-    scale = 64 ** -0.5
+    scale = geo.hd ** -0.5
     cos, sin = geo.rope[i]
     if i == 0:
         xn, mean_a, rstd_a = K.cast_bf16(x), None, None
     else:
         _, xn, mean_a, rstd_a = K.layernorm_fwd(x, w_an, geo.eps, False, True, want_stats)
+    if geo.hd != 64:
+        # head sizes 16 / 32: plain projection, rotary embedding as its own pass (fp32 on the bf16 projection, one rounding: the
+        # reference's order), attention on the generic kernels (csrc/attention_generic.hip); padded execution only
+        qkv = K.linear_fwd(xn, Wqkv_b)
+        K.rope_apply_generic_(qkv, cos, sin, B, S, nh, geo.hd, geo.per_batch_pos)
+        o, lse = K.attn_fwd_generic(qkv, geo.key_mask, B, S, nh, geo.hd, geo.windows[i], scale)
     # projection + RoPE in one kernel; the q third also takes the softmax's scale * log2(e) before its one bf16 rounding, so the
     # attention kernels exponentiate the MFMA's scores as they come (prescaled=True everywhere below)
-    qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos, q_scale=K.SOFTMAX_Q_SCALE)
-    if geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
+    elif geo.cu is not None:  # unpadded batch: packed rows, per-token rotary tables
+        qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos, q_scale=K.SOFTMAX_Q_SCALE)
         o, lse = K.attn_fwd_varlen(qkv, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, prescaled=True)
     else:
+        qkv = K.qkv_linear_rope(xn, Wqkv_b, cos, sin, S, geo.per_batch_pos, q_scale=K.SOFTMAX_Q_SCALE)
         o, lse = K.attn_fwd(qkv, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True)
         if geo.attn_out is not None and len(geo.attn_out) == i:  # output_attentions (not again when a checkpointed layer is recomputed)
             geo.attn_out.append(K.attn_probs(qkv, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, prescaled=True))
@@ -232,7 +241,7 @@ class _EncoderLayerFn(torch.autograd.Function):
     def backward(ctx, dy: Tensor):
         geo, i = ctx.geo, ctx.i
         B, S, nh = geo.B, geo.S, geo.nh
-        scale = 64 ** -0.5
+        scale = geo.hd ** -0.5
         need = ctx.needs_input_grad  # (geo, i, x, *weights)
         need_w = list(need[3:])
         if i == 0:
@@ -262,7 +271,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         do = K.linear_dgrad(gx16, Wo_b, Wo_t)
         dWo = K.linear_wgrad(gx16, o) if n_o else None
         # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
-        if geo.cu is not None:
+        if geo.hd != 64:
+            dqkv = K.attn_bwd_generic(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.hd, geo.windows[i], scale)
+            K.rope_apply_generic_(dqkv, geo.rope[i][0], geo.rope[i][1], B, S, nh, geo.hd, geo.per_batch_pos, inverse=True)
+        elif geo.cu is not None:
             dqkv = K.attn_bwd_varlen(qkv, o, do, lse, geo.cu, B, geo.max_s, nh, geo.windows[i], scale, geo.rope[i], prescaled=True)
         else:
             dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos,
@@ -411,7 +423,8 @@ class CM3PEncoder(nn.Module):
         key = (float(theta), str(device))
         if key not in self._inv_freq_cache:
             # TF:...modeling_modernbert.py:141, evaluated on the host exactly as the reference does
-            inv = 1.0 / (theta ** (torch.arange(0, 64, 2, dtype=torch.float) / 64))
+            hd = self.config.hidden_size // self.config.num_attention_heads
+            inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
             self._inv_freq_cache[key] = inv.to(device)
         return self._inv_freq_cache[key]
 
@@ -439,6 +452,13 @@ class CM3PEncoder(nn.Module):
         cfg = self.config
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if cfg.hidden_size // cfg.num_attention_heads != 64:
+            # the generic attention kernels (head_dim 16 / 32) know the padded layout only
+            if cu_seqlens is not None:
+                raise NotImplementedError("unpadded inputs need head_dim 64 (the generic attention kernels run padded batches)")
+            if output_attentions:
+                raise NotImplementedError("output_attentions needs head_dim 64")
+            unpad = False
         if cu_seqlens is not None:
             if output_attentions:
                 raise NotImplementedError("output_attentions with unpadded inputs: attention probabilities are (B, nh, S, S) tensors of a padded batch")
@@ -497,6 +517,7 @@ class CM3PEncoder(nn.Module):
         H = cfg.hidden_size
         geo = _Geometry()
         geo.B, geo.S, geo.H, geo.I, geo.nh, geo.L = B, S, H, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        geo.hd = H // cfg.num_attention_heads
         geo.eps = cfg.norm_eps
         geo.windows = [-1 if cfg.is_global_layer(i) else cfg.half_window for i in range(geo.L)]
         geo.key_mask = None

@@ -292,6 +292,33 @@ def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, w
     return out, lse
 
 
+# ---- head sizes other than 64 (csrc/attention_generic.hip: plain fp32 kernels so that every reference configuration runs)
+def attn_generic_supported(head_dim: int) -> bool:
+    return bool(query("cm3p_attn_generic_supported", int(head_dim)))
+
+
+def rope_apply_generic_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, hd: int, per_batch: bool, inverse: bool = False):
+    call("cm3p_rope_apply_generic", ptr(qkv, torch.bfloat16), ptr(cos, torch.float32), ptr(sin, torch.float32), B, S, nh, hd, S if per_batch else 0, int(inverse), stream())
+    return qkv
+
+
+def attn_fwd_generic(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, hd: int, window: int, scale: float):
+    out = torch.empty((B * S, nh * hd), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
+    call("cm3p_attn_fwd_generic", ptr(qkv, torch.bfloat16), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, hd, window, scale, stream())
+    return out, lse
+
+
+def attn_bwd_generic(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, hd: int,
+                     window: int, scale: float) -> Tensor:
+    """-> dqkv with the q / k thirds still in the ROTATED frame (rope_apply_generic_(..., inverse=True) finishes them)."""
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    call("cm3p_attn_bwd_generic", ptr(qkv, torch.bfloat16), ptr(out, torch.bfloat16), ptr(dout, torch.bfloat16), ptr(lse, torch.float32), ptr(delta), ptr(dqkv),
+         ptr(key_mask, torch.uint8), B, S, nh, hd, window, scale, stream())
+    return dqkv
+
+
 def attn_probs(qkv: Tensor, lse: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float, prescaled: bool = False) -> Tensor:
     """output_attentions: the probabilities [B, nh, S, S] fp32 of one layer, from qkv and the lse attn_fwd stored (inspection path)."""
     probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=qkv.device)

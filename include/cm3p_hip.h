@@ -215,6 +215,22 @@ int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,
                   const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* stream);
 
+/* Head sizes other than 64 (csrc/attention_generic.hip): the same attention contract - qkv [B, S, 3, nh, head_dim] bf16 with q and k already
+ * rotated, out [B, S, nh, head_dim] bf16, lse / delta [B, nh, S] fp32, the mask rule and the exact zeros / lse = +inf of rows without a
+ * visible key as cm3p_attn_fwd / cm3p_attn_bwd - as plain fp32 kernels (one thread per query or key row, no matrix cores) for head_dim 16
+ * and 32 (and 64, as a cross-check of the MFMA kernels).  They exist so that EVERY configuration of the reference runs, e.g. its own tiny
+ * test configuration (hidden 64, 4 heads; BASELINE.json configs[0]); the default towers are all head_dim 64 and never come here.  q is
+ * plain (no pre-scaling), dqkv's q / k thirds are gradients w.r.t. the ROTATED q / k: cm3p_rope_apply_generic(..., inverse = 1) on dqkv
+ * completes the backward of apply_rotary_pos_emb (TF:models/modernbert/modeling_modernbert.py:188-219), whose forward it also is
+ * (in place on the q and k thirds of a packed qkv; cos / sin [n_pos, head_dim / 2] from cm3p_rope_table). */
+int cm3p_attn_generic_supported(int head_dim);
+int cm3p_attn_fwd_generic(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int head_dim, int window,
+                          float scale, void* stream);
+int cm3p_attn_bwd_generic(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                          const uint8_t* key_mask, int B, int S, int nh, int head_dim, int window, float scale, void* stream);
+int cm3p_rope_apply_generic(void* qkv, const float* cos_tab, const float* sin_tab, int B, int S, int nh, int head_dim, int64_t pos_batch_stride,
+                            int inverse, void* stream);
+
 /* The same backward for GLOBAL layers (no window) as one key-parallel kernel that executes each of the five matrix products
  * once (cm3p_attn_bwd with window < 0 runs a query-parallel and a key-parallel kernel that both recompute the scores: seven).
  * Padded batches: cu_seqlens = NULL, total = 0, S = the padded length, key_mask [B, S] or NULL, lse [B, nh, S].

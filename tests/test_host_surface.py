@@ -122,8 +122,13 @@ def test_no_cpu_fallback():
 def test_unsupported_shapes_fail_loudly():
     from cm3p_amd import CM3PConfig, CM3PModel
 
+    # head_dim 16 (BASELINE configs[0], the reference's tiny test configuration) constructs since r04: the generic attention kernels
+    m16 = CM3PModel(CM3PConfig(**CASES["c1_tiny_nopad"]["cfg"]))
+    assert set(m16.state_dict()) == set(load_file(os.path.join(GOLD, "weights_c1.safetensors")))
+    bad = {**CASES["c1_tiny_nopad"]["cfg"]}
+    bad["beatmap_config"] = {**bad["beatmap_config"], "num_attention_heads": 8}  # head_dim 8: no kernel
     with pytest.raises(NotImplementedError, match="head_dim"):
-        CM3PModel(CM3PConfig(**CASES["c1_tiny_nopad"]["cfg"]))  # head_dim 16: CPU-only config (BASELINE configs[0])
+        CM3PModel(CM3PConfig(**bad))
     with pytest.raises(NotImplementedError):
         CM3PModel(CM3PConfig(has_decoder_head=True))  # loss_type None: the reference would silently use a causal-LM loss
     m = CM3PModel(CM3PConfig(**CASES["d64_mlm"]["cfg"]))

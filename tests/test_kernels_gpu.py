@@ -712,6 +712,84 @@ def test_attention_varlen_equals_padded_on_valid_rows(K, window):
     assert torch.equal(dqkv_p, dqkv.reshape(B * S, 3, nh, 64)[idx])
 
 
+@pytest.mark.parametrize("D,S,window,lens", [(16, 200, -1, None), (16, 333, 64, [333, 100]), (32, 130, 64, [130, 40]), (32, 512, -1, [512, 77]),
+                                             (64, 257, -1, [257, 200]), (64, 300, 64, None)])
+def test_generic_attention_matches_fp32_reference(K, D, S, window, lens):
+    """csrc/attention_generic.hip (head sizes 16 / 32; 64 as a cross-check): forward, lse and the three gradients against fp32 autograd
+    of softmax(scale q k^T + mask) v with the reference's mask rule (key padding AND |q - k| <= window; padded queries are not masked);
+    rows with no visible key give exact zeros and lse = +inf; at head_dim 64 the MFMA kernels must agree with it."""
+    g = torch.Generator().manual_seed(D + S)
+    nh = 2
+    B = len(lens) if lens else 2
+    scale = D ** -0.5
+    qkv = _bf(torch.randn(B, S, 3, nh, D, generator=g) * 0.8)
+    do = _bf(torch.randn(B * S, nh * D, generator=g) * 0.5)
+    mask = None
+    if lens is not None:
+        mask = (torch.arange(S)[None] < torch.tensor(lens)[:, None])
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))  # (B, nh, S, D)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    vis = torch.ones(B, 1, S, S, dtype=torch.bool)
+    if mask is not None:
+        vis = vis & mask[:, None, None, :]
+    if window >= 0:
+        idx = torch.arange(S)
+        vis = vis & ((idx[:, None] - idx[None, :]).abs() <= window)[None, None]
+    sc = sc.masked_fill(~vis, float("-inf"))
+    dead = ~vis.any(dim=-1)  # (B, 1, S)
+    p = torch.softmax(sc, dim=-1).masked_fill(dead[..., None], 0.0)
+    o = (p @ v).transpose(1, 2).reshape(B * S, nh * D)
+    o.backward(do.float())
+    lse_ref = torch.logsumexp(sc, dim=-1)  # -inf on dead rows (the kernels store +inf there)
+
+    km = mask.to(torch.uint8).to(DEV) if mask is not None else None
+    out, lse = K.attn_fwd_generic(qkv.to(DEV), km, B, S, nh, D, window, scale)
+    _assert_close(out, o.detach().to(torch.bfloat16), 2e-3, 2e-2, f"generic attn fwd D={D}")
+    dead_rows = dead.expand(B, nh, S)
+    live = ~dead_rows
+    assert torch.allclose(lse.cpu()[live], lse_ref[live], atol=2e-3, rtol=1e-4)
+    if dead_rows.any():
+        assert torch.isinf(lse.cpu()[dead_rows]).all() and (lse.cpu()[dead_rows] > 0).all()
+        assert out.view(B, S, nh, D).cpu().permute(0, 2, 1, 3)[dead_rows].abs().max().item() == 0.0
+    dqkv = K.attn_bwd_generic(qkv.to(DEV), out, do.to(DEV), lse, km, B, S, nh, D, window, scale)
+    want = x.grad
+    for i, nm in enumerate("qkv"):
+        e = (dqkv[:, :, i].float().cpu() - want[:, :, i]).norm() / want[:, :, i].norm().clamp_min(1e-9)
+        assert e < 1e-2, f"generic d{nm} relative L2 error {e:.3e}"
+    if mask is not None:  # padded keys receive exact zeros
+        assert dqkv[:, :, 1:].float().cpu()[~mask].abs().max().item() == 0.0
+    if D == 64:  # the MFMA kernels on the same inputs
+        out64, lse64 = K.attn_fwd(qkv.to(DEV), km, B, S, nh, window, scale)
+        _assert_close(out64, out, 2e-3, 2e-2, "MFMA vs generic forward")
+        d64 = K.attn_bwd(qkv.to(DEV), out64, do.to(DEV), lse64, km, B, S, nh, window, scale)
+        assert ((d64.float() - dqkv.float()).norm() / dqkv.float().norm()).item() < 1e-2
+
+
+@pytest.mark.parametrize("D", [16, 32, 64])
+def test_generic_rope_is_the_reference_rotation_and_its_transpose(K, D):
+    """cm3p_rope_apply_generic: q * cos + rotate_half(q) * sin in fp32 on the bf16 values (TF:models/modernbert/modeling_modernbert.py:188-219),
+    v untouched; inverse = 1 applies the transposed rotation (the backward)."""
+    g = torch.Generator().manual_seed(D)
+    B, S, nh = 2, 37, 3
+    qkv = _bf(torch.randn(B, S, 3, nh, D, generator=g))
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    cos, sin = K.rope_table(torch.arange(S, device=DEV), inv_freq.to(DEV))
+    c = torch.cat((cos.cpu(), cos.cpu()), -1)[None, :, None, :]  # (1, S, 1, D)
+    s_ = torch.cat((sin.cpu(), sin.cpu()), -1)[None, :, None, :]
+    rot = lambda t: torch.cat((-t[..., D // 2:], t[..., :D // 2]), -1)
+    x = qkv.float()
+    want = x.clone()
+    want[:, :, :2] = x[:, :, :2] * c.unsqueeze(2) + rot(x[:, :, :2]) * s_.unsqueeze(2)
+    got = K.rope_apply_generic_(qkv.clone().to(DEV), cos, sin, B, S, nh, D, False)
+    assert torch.equal(got[:, :, 2].cpu(), qkv[:, :, 2])
+    assert (got.float().cpu() - want).abs().max().item() <= 2e-2  # one bf16 rounding of O(1) values
+    back = x.clone()
+    back[:, :, :2] = x[:, :, :2] * c.unsqueeze(2) - rot(x[:, :, :2]) * s_.unsqueeze(2)
+    got_inv = K.rope_apply_generic_(qkv.clone().to(DEV), cos, sin, B, S, nh, D, False, inverse=True)
+    assert (got_inv.float().cpu() - back).abs().max().item() <= 2e-2
+
+
 def test_gather_scatter_rows(K):
     x = torch.randn(37, 64, device=DEV)
     idx = torch.tensor([5, 0, 36, 7, 8], device=DEV)

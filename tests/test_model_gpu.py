@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda"
-GPU_CASES = [n for n in CASES if n.startswith("d64")]
+GPU_CASES = [n for n in CASES if n.startswith("d64") or n.startswith("c1")]  # c1: head_dim 16, on the generic attention kernels since r04
 
 
 def _rel(a, b):
@@ -34,7 +34,7 @@ def _build(name, dtype=torch.float32):
 
     cfg = CM3PConfig(**CASES[name]["cfg"])
     model = CM3PModel(cfg)
-    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
+    sd = load_file(os.path.join(GOLD, "weights_c1.safetensors" if name.startswith("c1") else "weights_d64.safetensors"))
     blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
     sd.update({k[2:]: v for k, v in blob.items() if k.startswith("w.")})  # parameters only this case has (MLM head)
     model.load_state_dict(sd, strict=True)
@@ -643,7 +643,7 @@ def test_extraction_and_variation_eval_paths():
 
 # ------------------------------------------------------------------------------------------------- stand-alone classes
 def _load_into(model, name="d64_mlm"):
-    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
+    sd = load_file(os.path.join(GOLD, "weights_c1.safetensors" if name.startswith("c1") else "weights_d64.safetensors"))
     sd.update({k[2:]: v for k, v in load_file(os.path.join(GOLD, f"{name}.safetensors")).items() if k.startswith("w.")})
     own = model.state_dict()
     model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=True)
@@ -700,7 +700,7 @@ def test_classifier_variant_matches_reference_fixture(tag, num_labels):
     bc.num_labels = num_labels
     bc.problem_type = None
     model = CM3PForBeatmapClassification(bc)
-    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
+    sd = load_file(os.path.join(GOLD, "weights_c1.safetensors" if name.startswith("c1") else "weights_d64.safetensors"))
     sd = {k: v for k, v in sd.items() if k in model.state_dict()}
     sd["classifier.weight"] = gold[f"{tag}.w.classifier.weight"]
     sd["classifier.bias"] = gold[f"{tag}.w.classifier.bias"]

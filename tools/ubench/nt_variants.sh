@@ -5,7 +5,7 @@ R=$(pwd); C=$R/cm3p_amd/csrc; O=$R/_ab; mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-inline-asm"
 for m in "$@"; do
   mkdir -p $O/nt_$m
-  for f in norm elementwise gemm gemm256 gemm8p attention attention_bwd attention_bwd_fused head conv muon; do
+  for f in norm elementwise gemm gemm256 gemm8p attention attention_bwd attention_bwd_fused attention_generic head conv muon; do
     x=""; case $f in attention_bwd|attention_bwd_fused) x="-fno-slp-vectorize";; esac
     /opt/rocm/bin/hipcc $FLAGS $x -DCM3P_NT=$m -c $C/$f.hip -o $O/nt_$m/$f.o &
   done
