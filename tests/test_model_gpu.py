@@ -643,7 +643,7 @@ def test_extraction_and_variation_eval_paths():
 
 # ------------------------------------------------------------------------------------------------- stand-alone classes
 def _load_into(model, name="d64_mlm"):
-    sd = load_file(os.path.join(GOLD, "weights_c1.safetensors" if name.startswith("c1") else "weights_d64.safetensors"))
+    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
     sd.update({k[2:]: v for k, v in load_file(os.path.join(GOLD, f"{name}.safetensors")).items() if k.startswith("w.")})
     own = model.state_dict()
     model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=True)
@@ -700,7 +700,7 @@ def test_classifier_variant_matches_reference_fixture(tag, num_labels):
     bc.num_labels = num_labels
     bc.problem_type = None
     model = CM3PForBeatmapClassification(bc)
-    sd = load_file(os.path.join(GOLD, "weights_c1.safetensors" if name.startswith("c1") else "weights_d64.safetensors"))
+    sd = load_file(os.path.join(GOLD, "weights_d64.safetensors"))
     sd = {k: v for k, v in sd.items() if k in model.state_dict()}
     sd["classifier.weight"] = gold[f"{tag}.w.classifier.weight"]
     sd["classifier.bias"] = gold[f"{tag}.w.classifier.bias"]
