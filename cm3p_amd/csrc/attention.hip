@@ -743,13 +743,12 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     if (stages & CM3P_ATTN_BWD_DQ) {
 #define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        static const bool attr = [] {
+        static Cm3pDevOnce once;  // (per device: common.h)
+        if (once.first()) {
             const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>),
                                 reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>)};
             for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSlots * kDqStage);
-            return true;
-        }();
-        (void)attr;
+        }
         if (pre && key_mask) attn_bwd_dq_kernel<true, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
         else if (pre) attn_bwd_dq_kernel<true, false><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
         else if (key_mask) attn_bwd_dq_kernel<false, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
@@ -759,12 +758,11 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     }
     if (stages & CM3P_ATTN_BWD_DKV) {
 #define CM3P_DKV_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
-        static const bool attr2 = [] {
+        static Cm3pDevOnce once2;
+        if (once2.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
-            return true;
-        }();
-        (void)attr2;
+        }
         if (pre) attn_bwd_dkv_kernel<true><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
         else attn_bwd_dkv_kernel<false><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
 #undef CM3P_DKV_ARGS

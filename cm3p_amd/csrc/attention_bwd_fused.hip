@@ -755,14 +755,13 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
     const bool run_even = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_EVEN);
     const bool run_odd = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_ODD);
     if (run_even || run_odd) {
-        static const bool attr = [] {
+        static Cm3pDevOnce once;  // (per device: common.h)
+        if (once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-            return true;
-        }();
-        (void)attr;
+        }
         // two launches: the even key blocks store their dQ partial, then the odd ones add theirs to the same slab (1-D grids:
         // decode_block() maps them XCD-aware)
         const int nkb = (S + 255) / 256;

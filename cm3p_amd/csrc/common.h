@@ -31,7 +31,7 @@ struct BatchArgs {
 // r04 "output stores").  Bit mask so that variants can be built for an A/B (tools/ubench/nt_variants.sh):
 //   1 gemm8p bf16 epilogues   2 fused attention backward: dQ partial slabs   4 attention outputs written through store_rows32
 //   8 dQ slab reduce (slab loads and dq stores)   16 LayerNorm / GeGLU outputs   32 gemm8p fp32 epilogues
-//   64 gemm8p residual loads (read once)
+//   64 gemm8p residual loads (read once)   128 LayerNorm / GeGLU input rows (read once)
 #ifndef CM3P_NT
 #define CM3P_NT 7
 #endif
@@ -63,6 +63,15 @@ __device__ __forceinline__ uint4 gload16(const void* p) {
     }
 }
 
+template <bool NT>
+__device__ __forceinline__ uint2 gload8(const void* p) {
+    if constexpr (NT) {
+        const cm3p_u32x2 v = __builtin_nontemporal_load(static_cast<const cm3p_u32x2*>(p));
+        return uint2{v[0], v[1]};
+    } else {
+        return *static_cast<const uint2*>(p);
+    }
+}
 template <bool NT>
 __device__ __forceinline__ __attribute__((ext_vector_type(4))) float gload16f(const void* p) {
     typedef __attribute__((ext_vector_type(4))) float f4;
@@ -119,6 +128,34 @@ __device__ __forceinline__ void cm3p_audit(int id, const void* first_byte, int b
     do {                                     \
         if (!(cond)) return CM3P_ERR_INVALID; \
     } while (0)
+
+// A kernel's MaxDynamicSharedMemorySize attribute and the CU count belong to a DEVICE, and one process may drive several (a model moved
+// to cuda:1, DataParallel): once-per-process statics would launch on the second device without the attribute and with the first
+// device's grid (r03 advisor).  (Not thread-safe beyond what a benign double initialisation is.)
+constexpr int kCm3pMaxDevices = 64;
+static inline int cm3p_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kCm3pMaxDevices) d = 0;
+    return d;
+}
+static inline int cm3p_num_cu() {
+    static int cu[kCm3pMaxDevices];
+    const int d = cm3p_current_device();
+    if (cu[d] == 0) {
+        hipDeviceProp_t prop;
+        cu[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cu[d];
+}
+struct Cm3pDevOnce {  // `static Cm3pDevOnce once; if (once.first()) { ... }`: the body runs once per device
+    bool done[kCm3pMaxDevices] = {};
+    bool first() {
+        const int d = cm3p_current_device();
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
 
 static inline bool cm3p_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

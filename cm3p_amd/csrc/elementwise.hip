@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restri
         const int64_t t = i / c8;
         const int c = (int)(i % c8);
         float a[8], b[8], y[8];
-        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + c * 8), a);
-        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + I + c * 8), b);
+        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
+        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = gelu_erf(a[j]) * b[j];
         gstore16<(CM3P_NT & 16) != 0>(g + t * I + c * 8, pack8(y));
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restri
         const int64_t t = i / c8;
         const int c = (int)(i % c8);
         float a[8], b[8], d[8], da[8], db[8];
-        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + c * 8), a);
-        unpack8(*reinterpret_cast<const uint4*>(h + t * 2 * I + I + c * 8), b);
-        unpack8(*reinterpret_cast<const uint4*>(dg + t * I + c * 8), d);
+        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
+        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
+        unpack8(gload16<(CM3P_NT & 128) != 0>(dg + t * I + c * 8), d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             da[j] = d[j] * b[j] * gelu_erf_grad(a[j]);

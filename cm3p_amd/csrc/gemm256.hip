@@ -399,23 +399,16 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
               int64_t ldb, int64_t ldc, int epi, int splits, int64_t kchunk, int64_t c_split_stride, hipStream_t s, RopeArgs rope) {
     const int tiles_m = (int)((M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
     const int ntiles = tiles_m * tiles_n, total = ntiles * splits;
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-        if (num_cu <= 0) num_cu = 256;
-    }
+    const int num_cu = cm3p_num_cu();
     const dim3 grid(total < num_cu ? total : num_cu);  // one persistent 512-thread workgroup per CU
     const size_t lds = 2 * kStage;
 #define CM3P_G256(E)                                                                                                     \
     {                                                                                                                    \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
+        static Cm3pDevOnce once;                                                                                         \
+        if (once.first()) {                                                                                              \
             if (hipFuncSetAttribute((const void*)gemm256_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds) != hipSuccess)                                                             \
                 return CM3P_ERR_LAUNCH;                                                                                  \
-            attr_set = true;                                                                                             \
         }                                                                                                                \
         gemm256_kernel<A_KC, B_KC, E><<<grid, kThreads, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }

@@ -612,13 +612,7 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
              int batch) {
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     const int ntiles = tiles_m * tiles_n, total = ntiles * (batch > 0 ? batch : splits);
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-        if (num_cu <= 0) num_cu = 256;
-    }
+    const int num_cu = cm3p_num_cu();
     int want = num_cu;
     if (const char* e = getenv("CM3P_G8P_GRID")) {  // development switch: leave CUs to a kernel on another stream (tools/overlap_ab.py)
         const int g = atoi(e);
@@ -627,11 +621,10 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
     const dim3 grid(total < want ? total : want);
 #define CM3P_G8P(E)                                                                                                               \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
+        static Cm3pDevOnce once;                                                                                                  \
+        if (once.first()) {                                                                                                       \
             if (hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E, REBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
                 return CM3P_ERR_LAUNCH;                                                                                           \
-            attr_set = true;                                                                                                      \
         }                                                                                                                         \
         gemm8p_kernel<A_KC, B_KC, E, REBAL><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope, bt, batch > 0 ? 1 : 0); \
     }

@@ -27,11 +27,12 @@ __device__ __forceinline__ void load_row(RowRegs<NC>& r, const void* src, int H,
     for (int c = 0; c < NC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < H) {
+            // (CM3P_NT bit 128: read-once streams as non-temporal loads - an r04 probe)
             if constexpr (SRC_BF16) {
-                const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(src) + col);
+                const uint2 w = gload8<(CM3P_NT & 128) != 0>(static_cast<const uint16_t*>(src) + col);
                 r.v[c] = f32x4{bf16lo(w.x), bf16hi(w.x), bf16lo(w.y), bf16hi(w.y)};
             } else {
-                r.v[c] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + col);
+                r.v[c] = gload16f<(CM3P_NT & 128) != 0>(static_cast<const float*>(src) + col);
             }
         } else {
             r.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -238,8 +238,8 @@ int cm3p_rope_apply_generic(void* qkv, const float* cos_tab, const float* sin_ta
  * tables per token (as cm3p_attn_bwd_varlen).
  * stages: CM3P_ATTN_BWD_FUSED_PREP (delta and the per-tile score offsets -> workspace), _MAIN (dk and dv thirds of dqkv; one bf16
  * partial dq per PAIR of 256-key blocks -> workspace: two launches, see _MAIN_EVEN / _MAIN_ODD), _REDUCE (the dq third of dqkv from
- * the partials, summed in fp32 in a fixed order:
- * deterministic); a caller issues all three in this order on one stream (7), or one by one to time them.
+ * the partials: the two key blocks of a slab are summed in bf16 by the memory side's packed add (_MAIN_ODD, one more rounding than a
+ * pure fp32 sum), the slabs in fp32 in a fixed order by _REDUCE: deterministic); a caller issues all three in this order on one stream (7), or one by one to time them.
  * workspace: caller-owned device memory of at least cm3p_attn_bwd_fused_workspace_bytes(B, S, nh) bytes, 16-byte aligned;
  * contents are scratch (nothing is carried between calls). */
 #define CM3P_ATTN_BWD_FUSED_PREP 1
