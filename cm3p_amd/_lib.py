@@ -86,6 +86,7 @@ SIGNATURES = {
     "cm3p_pointwise_loss": [_P, _P, _P, _P, _L, _I, _P],
     "cm3p_attn_fwd_varlen": [_P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _I, _P],
     "cm3p_attn_bwd_fused_workspace_bytes": [_I, _I, _I],
+    "cm3p_attn_bwd_fused_slab_group": [_I],
     "cm3p_attn_bwd_fused": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _L, _I, _I, _P, _L, _P],
     "cm3p_attn_bwd_varlen": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _I, _P],
     "cm3p_gather_rows_f32": [_P, _P, _P, _L, _I, _P],

@@ -61,7 +61,7 @@ constexpr int kFPadTiles = 12;              // statistics tiles past ceil(S / 64
 
 __host__ __device__ inline int64_t fused_stat_floats(int B, int S, int nh) { return (int64_t)B * nh * ((S + 63) / 64 + kFPadTiles) * 128; }
 __host__ __device__ inline int fused_slab_rows(int S) { return ((S + 63) / 64) * 64 + 64; }
-__host__ __device__ inline int fused_slabs(int S) { return ((S + 255) / 256 + 1) / 2; }  // key blocks 2 j and 2 j + 1 share slab j
+__host__ __device__ inline int fused_slabs(int S, int G = 2) { return ((S + 255) / 256 + G - 1) / G; }  // key blocks G j .. G j + G - 1 share slab j
 
 __device__ __forceinline__ bf16x8 gload_frag8(const uint16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -128,11 +128,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
 __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int t, int head, int b,
                                                int tid, const SeqView& sv, int Smax, int nh, float scale,
                                                const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                               int64_t pos_batch_stride) {
+                                               int64_t pos_batch_stride, int G) {
     const int S = sv.S;
     const int row = t * 64 + (tid >> 2), j = tid & 3;
     if (row >= S) return;
-    const int nkb = fused_slabs(Smax), nkb_b = fused_slabs(S);  // (slabs, not key blocks: two key blocks share one)
+    const int nkb = fused_slabs(Smax, G), nkb_b = fused_slabs(S, G);  // (slabs, not key blocks: G key blocks share one)
     const int64_t slab = (int64_t)fused_slab_rows(Smax) * 64;
     const uint16_t* p = dq_part + ((int64_t)b * nh + head) * nkb * slab + (int64_t)row * 64 + 8 * j;
     float lo[8], hi[8];
@@ -180,10 +180,10 @@ __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_p
 // the reduction as its own launch: grid (tiles, nh, B), 256 threads
 __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int Smax,
                                                                  int nh, float scale, const float* __restrict__ rope_cos,
-                                                                 const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+                                                                 const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl, int G) {
     const int head = blockIdx.y, b = blockIdx.z;
     const SeqView sv(vl, b, head, Smax, nh);
-    dq_reduce_tile(dq_part, dqkv, blockIdx.x, head, b, threadIdx.x, sv, Smax, nh, scale, rope_cos, rope_sin, pos_batch_stride);
+    dq_reduce_tile(dq_part, dqkv, blockIdx.x, head, b, threadIdx.x, sv, Smax, nh, scale, rope_cos, rope_sin, pos_batch_stride, G);
 }
 
 // ---- fused ----------------------------------------------------------------------------------------------------------------------
@@ -192,16 +192,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
                                                                 const float* __restrict__ stat_ws, uint16_t* __restrict__ dq_part,
                                                                 uint16_t* __restrict__ dqkv, const uint8_t* __restrict__ kmask, int Smax,
                                                                 int nh, float scale, const float* __restrict__ rope_cos,
-                                                                const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
+                                                                const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl, int G,
+                                                                int phase) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (tells the compiler that everything derived from it is wave-uniform)
     const int nkb = (Smax + 255) / 256, NT = (Smax + 63) / 64;
-    // this launch's key blocks: the even ones (they store their dQ partial) or, ADD, the odd ones (they add it to the same slab)
-    const int nblk = ADD ? nkb / 2 : (nkb + 1) / 2;
+    // this launch's key blocks: G k + phase.  Phase 0 (!ADD) stores its dQ partial to slab k, the phases 1 .. G - 1 (ADD, one launch
+    // each, stream-ordered) add theirs to the same slab
+    const int nblk = (nkb - phase + G - 1) / G;
     int kblk, head, b;
     decode_block(nblk, nh, kblk, head, b);
-    kblk = 2 * kblk + (ADD ? 1 : 0);
+    const int slab_idx = kblk;
+    kblk = G * kblk + phase;
     const int K0 = kblk * 256;
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     using I8 = std::integral_constant<int, 8>;
     using I12 = std::integral_constant<int, 12>;
     // this key block's slab: rows = query rows, 64 * NT real rows + 64 dump rows
-    uint16_t* const slab_u = dq_part + (((int64_t)b * nh + head) * fused_slabs(Smax) + (kblk >> 1)) * ((int64_t)fused_slab_rows(Smax) * 64) + 32 * dq_db;
+    uint16_t* const slab_u = dq_part + (((int64_t)b * nh + head) * fused_slabs(Smax, G) + slab_idx) * ((int64_t)fused_slab_rows(Smax) * 64) + 32 * dq_db;
     uint16_t* const slab = slab_u + (lane >> 2) * 64 + 8 * (lane & 3);
     uint16_t* srow = slab;
     // ADD: one dword per lane and instruction - lane l adds dword l & 15 of row 4 j + (l >> 4) of the block, j = 0 .. 7, i.e. four
@@ -720,6 +723,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
 
 extern "C" {
 
+int cm3p_attn_bwd_fused_slab_group(int S) { return (S + 255) / 256 >= 24 ? 4 : 2; }
+
 int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh) {
     if (B <= 0 || S <= 0 || nh <= 0) return 0;
     const int64_t stats = (fused_stat_floats(B, S, nh) * 4 + 255) / 256 * 256;
@@ -731,7 +736,7 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
                         const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* workspace,
                         int64_t workspace_bytes, void* stream) {
     CM3P_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr));
-    CM3P_REQUIRE(stages >= 1 && stages <= 31);
+    CM3P_REQUIRE(stages >= 1 && stages <= 255);
     CM3P_REQUIRE(qkv && out && dout && lse && dqkv && workspace && B > 0 && S > 0 && nh > 0 && scale > 0.f);
     CM3P_REQUIRE(cm3p_aligned16(qkv) && cm3p_aligned16(out) && cm3p_aligned16(dout) && cm3p_aligned16(dqkv) && cm3p_aligned16(workspace));
     if (cu_seqlens) CM3P_REQUIRE(total > 0 && key_mask == nullptr && pos_batch_stride == 0);
@@ -744,6 +749,12 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
     uint16_t* dq_part = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + (fused_stat_floats(B, S, nh) * 4 + 255) / 256 * 256);
     const int NT = (S + 63) / 64;
     const bool pre = q_prescaled != 0;
+    // Key blocks per dQ slab: 2, or 4 from 24 key blocks (S > 5888) on.  Four halve the slabs the reduce pass reads (C4: 6.3 -> 3.1 ms
+    // per step) and put three of four launches on the packed-bf16 atomic path (2-8 % slower than the storing one, and one rounding per
+    // add): r04 one-call A/B C4 214.6 -> 213.2 ms, C2 (16 key blocks) 168.8 vs 168.8 - hence the length rule.  CM3P_FUSED_SLAB_GROUP=2 / 4
+    // overrides (read per call).  The workspace is sized for 2, the larger.
+    const char* env_g = getenv("CM3P_FUSED_SLAB_GROUP");
+    const int G = (env_g && (env_g[0] == '2' || env_g[0] == '4')) ? env_g[0] - '0' : cm3p_attn_bwd_fused_slab_group(S);
     if (stages & CM3P_ATTN_BWD_FUSED_PREP) {
         // the score accumulators start at -lse * log2(e) (pre: q carries scale * log2 e, the MFMA delivers log2 p) or at
         // -lse / scale (cm * (q.k - lse / scale) = log2 p)
@@ -754,7 +765,7 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
     }
     const bool run_even = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_EVEN);
     const bool run_odd = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_ODD);
-    if (run_even || run_odd) {
+    if (run_even || run_odd || (stages & (7 * CM3P_ATTN_BWD_FUSED_MAIN_ADD1))) {
         static Cm3pDevOnce once;  // (per device: common.h)
         if (once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
@@ -762,25 +773,27 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
         }
-        // two launches: the even key blocks store their dQ partial, then the odd ones add theirs to the same slab (1-D grids:
-        // decode_block() maps them XCD-aware)
+        // G launches: the key blocks G k store their dQ partial to slab k, then the key blocks G k + 1, .. each add theirs to it (1-D
+        // grids: decode_block() maps them XCD-aware)
         const int nkb = (S + 255) / 256;
-        const dim3 grid_even(((nkb + 1) / 2) * nh * B), grid_odd((nkb / 2) * nh * B);
-#define CM3P_FUSED_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, stat_ws, dq_part, (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl
+#define CM3P_FUSED_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, stat_ws, dq_part, (uint16_t*)dqkv, key_mask, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl, G
         if (run_even) {
-            if (pre) attn_bwd_fused_kernel<true, false><<<grid_even, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
-            else attn_bwd_fused_kernel<false, false><<<grid_even, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+            const dim3 grid0(((nkb + G - 1) / G) * nh * B);
+            if (pre) attn_bwd_fused_kernel<true, false><<<grid0, 256, kFLds, s>>>(CM3P_FUSED_ARGS, 0);
+            else attn_bwd_fused_kernel<false, false><<<grid0, 256, kFLds, s>>>(CM3P_FUSED_ARGS, 0);
             if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
         }
-        if (run_odd && nkb > 1) {
-            if (pre) attn_bwd_fused_kernel<true, true><<<grid_odd, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
-            else attn_bwd_fused_kernel<false, true><<<grid_odd, 256, kFLds, s>>>(CM3P_FUSED_ARGS);
+        for (int phase = 1; phase < G && phase < nkb; ++phase) {
+            if (!(run_odd || (stages & (CM3P_ATTN_BWD_FUSED_MAIN_ADD1 << (phase - 1))))) continue;
+            const dim3 gridp(((nkb - phase + G - 1) / G) * nh * B);
+            if (pre) attn_bwd_fused_kernel<true, true><<<gridp, 256, kFLds, s>>>(CM3P_FUSED_ARGS, phase);
+            else attn_bwd_fused_kernel<false, true><<<gridp, 256, kFLds, s>>>(CM3P_FUSED_ARGS, phase);
             if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;
         }
 #undef CM3P_FUSED_ARGS
     }
     if (stages & CM3P_ATTN_BWD_FUSED_REDUCE) {
-        attn_bwd_dq_reduce_kernel<<<dim3(NT, nh, B), 256, 0, s>>>(dq_part, (uint16_t*)dqkv, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl);
+        attn_bwd_dq_reduce_kernel<<<dim3(NT, nh, B), 256, 0, s>>>(dq_part, (uint16_t*)dqkv, S, nh, scale, cos_tab, sin_tab, pos_batch_stride, vl, G);
     }
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;

@@ -337,7 +337,8 @@ def _attn_tag(fmt: str, window: int, prescaled: bool, varlen: bool = False) -> s
 
 
 ATTN_BWD_FUSED_PREP, ATTN_BWD_FUSED_MAIN, ATTN_BWD_FUSED_REDUCE = 1, 2, 4  # stages of cm3p_attn_bwd_fused
-ATTN_BWD_FUSED_MAIN_EVEN, ATTN_BWD_FUSED_MAIN_ODD = 8, 16  # the two launches of _MAIN (even key blocks store, odd ones add)
+ATTN_BWD_FUSED_MAIN_EVEN, ATTN_BWD_FUSED_MAIN_ODD = 8, 16  # the storing launch of _MAIN (first key block of every slab group) and all adding ones
+ATTN_BWD_FUSED_MAIN_ADD1 = 32  # the adding launches one by one: _ADD1 << (p - 1) = position p of the group
 _fused_ws: dict = {}  # (device index, stream) -> byte tensor: the fused backward's workspace, grown on demand, shared by all layers
 
 
@@ -370,16 +371,20 @@ def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, r
     varlen = cu is not None
     rows = total if varlen else B * S
     fl = 2.0 * B * nh * S * S * 64  # one S x S x 64 product per (batch, head); SURVEY.md 8(d) credits four to the backward
-    nkb = -(-S // 256)  # 256-key blocks: the even ones are one launch, the odd ones the next
-    slabs = float(need)
+    nkb = -(-S // 256)  # 256-key blocks; G of them share a dQ slab: the first of each group stores (one launch), the others add (G - 1 launches)
+    env_g = os.environ.get("CM3P_FUSED_SLAB_GROUP", "")
+    G = int(env_g) if env_g in ("2", "4") else query("cm3p_attn_bwd_fused_slab_group", S)
+    n_store = -(-nkb // G)
+    slabs = float(need) * 2.0 / G  # (the workspace is sized for groups of 2)
+    # one C call per launch, so that every profiler tag is ONE kernel (one rocprof row): the storing launch, then the adding launches
+    adds = [(ATTN_BWD_FUSED_MAIN_ADD1 << (p - 1), "attn_bwd_fused_kernel<%s, true>", 4.0 * fl * len(range(p, nkb, G)) / nkb)
+            for p in range(1, min(G, nkb))]
     for stage, name, work in (
         (ATTN_BWD_FUSED_PREP, "attn_bwd_prep_kernel", 2.0 * rows * nh * 64 * 2 + 12.0 * rows * nh),
-        (ATTN_BWD_FUSED_MAIN_EVEN, "attn_bwd_fused_kernel<%s, false>", 4.0 * fl * (-(-nkb // 2)) / nkb),
-        (ATTN_BWD_FUSED_MAIN_ODD, "attn_bwd_fused_kernel<%s, true>", 4.0 * fl * (nkb // 2) / nkb),
+        (ATTN_BWD_FUSED_MAIN_EVEN, "attn_bwd_fused_kernel<%s, false>", 4.0 * fl * n_store / nkb),
+        *adds,
         (ATTN_BWD_FUSED_REDUCE, "attn_bwd_dq_reduce_kernel", slabs + rows * nh * 64 * 2.0),
     ):
-        if stage == ATTN_BWD_FUSED_MAIN_ODD and nkb < 2:
-            continue  # (a single key block: nothing for the second launch)
         call("cm3p_attn_bwd_fused", ptr(qkv), ptr(out), ptr(dout), ptr(lse, torch.float32), ptr(dqkv), ptr(key_mask, torch.uint8),
              ptr(cu, torch.int32), B, S, total if varlen else 0, nh, scale, ptr(cos, torch.float32), ptr(sin, torch.float32),
              S if (per_batch and not varlen) else 0, stage, int(prescaled), ptr(ws), ws.numel(), stream(),

@@ -245,10 +245,15 @@ int cm3p_rope_apply_generic(void* qkv, const float* cos_tab, const float* sin_ta
 #define CM3P_ATTN_BWD_FUSED_PREP 1
 #define CM3P_ATTN_BWD_FUSED_MAIN 2      /* = _MAIN_EVEN then _MAIN_ODD */
 #define CM3P_ATTN_BWD_FUSED_REDUCE 4
-#define CM3P_ATTN_BWD_FUSED_MAIN_EVEN 8 /* the main kernel over key blocks 0, 2, 4 ...: each STORES its bf16 dq partial to slab kblk / 2 */
-#define CM3P_ATTN_BWD_FUSED_MAIN_ODD 16 /* ... over key blocks 1, 3, 5 ...: each ADDS its partial to the same slab (one packed-bf16 atomic
+#define CM3P_ATTN_BWD_FUSED_MAIN_EVEN 8 /* the main kernel over key blocks 0, G, 2 G ... (G = cm3p_attn_bwd_fused_slab_group): each STORES its bf16 dq partial to slab kblk / G */
+#define CM3P_ATTN_BWD_FUSED_MAIN_ODD 16 /* ... over the other key blocks, one launch per position in the group: each ADDS its partial to the same slab (one packed-bf16 atomic
                                            add per element, after the store by stream order: deterministic); must follow _MAIN_EVEN */
+#define CM3P_ATTN_BWD_FUSED_MAIN_ADD1 32 /* the adding launches one by one (callers that time kernels): _ADD1 << (p - 1) = position p of the group, p = 1 .. G - 1 */
 int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh);
+/* Host-only: how many consecutive 256-key blocks share one dQ slab at sequence length S (2, or 4 for long sequences: the first block of
+ * a group stores its partial, the others add theirs with packed-bf16 atomics in launches of their own; the environment variable
+ * CM3P_FUSED_SLAB_GROUP=2|4 overrides).  _MAIN_EVEN = the storing launch, _MAIN_ODD = the adding launches, in order. */
+int cm3p_attn_bwd_fused_slab_group(int S);
 int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* key_mask,
                         const int* cu_seqlens, int B, int S, int64_t total, int nh, float scale, const float* cos_tab,
                         const float* sin_tab, int64_t pos_batch_stride, int stages, int q_prescaled, void* workspace,
