@@ -59,11 +59,6 @@ __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_
         asm volatile("" ::"v"(voff), "s"(sbase), "s"(ldsw));
         return;
     }
-    if constexpr ((CM3P_NT & 256) != 0 && AUD == CM3P_AUD_A) {  // r04 probe: the A operand's stream as non-temporal loads
-        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(ldsw), "n"(IMM)
-                     : "memory", "m0", "scc");
-        return;
-    }
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsw), "n"(IMM)
                  : "memory", "m0", "scc");
 }
