@@ -168,15 +168,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
 }
 
-// out[col] = sum_b partial[b][col], fixed summation order.  Block = 32 columns x 8 row slices; each thread keeps 8
-// independent loads in flight, slices are combined through LDS in slice order (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
-    __shared__ float red[8][33];
+// out[col] = sum_b partial[b][col], fixed summation order.  Block = 32 columns x 32 row slices (1024 threads: the 24 workgroups
+// this launch has at H = 768 sit between two kernels of the backward chain, so its time is the depth of its dependent load rounds -
+// 4 rounds of 8 loads per thread at 1024 partial rows, 16 in the 8-slice form of r01-r03: 17.6 -> ~6 us per launch);
+// slices are combined through LDS in slice order (deterministic).
+constexpr int kColsumSlices = 32;
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
+    __shared__ float red[kColsumSlices][33];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cx;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < H) {
-        const int per = (nblk + 7) / 8;
+        const int per = (nblk + kColsumSlices - 1) / kColsumSlices;
         const int b0 = slice * per, b1 = min(nblk, b0 + per);
         int b = b0;
         for (; b + 8 <= b1; b += 8) {
@@ -188,10 +191,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
     red[slice][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (slice == 0 && col < H) {
-        float s = 0.f;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += red[i][cx];
-        out[col] = s;
+        for (int i = 0; i < kColsumSlices; i += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += red[i + u][cx];
+        }
+        out[col] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
 }
 
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(1024) void audio_slots_kernel(const int64_t* __rest
 //   2. per key the exclusive prefix of cnt over the blocks and the key's total, then an exclusive scan of the totals over the keys:
 //      key start + prefix = the first sorted position of each (key, block) pair;
 //   3. each block hands its tokens their positions in token order (one wave walks the block 64 tokens at a time; within a wave
-//      the lanes that share a key rank themselves with a ballot), writing order[] and the sorted keys;
+//      the lanes that share a key find each other with one ballot per key bit), writing order[] and the sorted keys;
 //   4. run starts from the sorted keys and their running count (two launches over blocks of 1024 positions).
 constexpr int kOrdBlock = 1024;     // tokens per block of the histogram / scatter kernels
 constexpr int kOrdMaxKeys = 12288;  // LDS: one int per key
@@ -574,22 +580,22 @@ __global__ __launch_bounds__(64) void token_scatter_kernel(const int64_t* __rest
             const int64_t id = ids[t];
             key = (int)(id < 0 ? -1 : (id > vocab ? vocab : id)) + 1;
         }
-        // the lanes of a key, lowest token first, take consecutive positions; one round per distinct key of these 64 tokens
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int k = __shfl(key, leader, 64);
-            const unsigned long long same = __ballot(live && key == k);
-            // (a wave's LDS operations execute in order: every lane's read of next[k] precedes the leader's update; volatile keeps the
-            //  compiler from carrying a value of next[] across rounds)
-            volatile int* nk = next + k;
-            if (live && key == k) {
-                const int pos = *nk + __popcll(same & ((1ull << lane) - 1ull));
-                order[pos] = t;
-                sorted_key[pos] = k;
-            }
-            if (lane == leader) *nk += __popcll(same);
-            todo &= ~same;
+        // the lanes that share a key, found without a loop over the keys: AND over the key's bits of "lanes whose bit equals mine"
+        // (14 ballots cover kOrdMaxKeys); the lowest such lane leads.  Lanes of a key, lowest token first, take consecutive positions.
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 14; ++b) {
+            const unsigned long long set = __ballot((key >> b) & 1);
+            same &= ((key >> b) & 1) ? set : ~set;
+        }
+        // (a wave's LDS operations execute in order: every lane's read of next[key] precedes the leader's update; volatile keeps the
+        //  compiler from carrying a value of next[] across chunks)
+        if (live) {
+            volatile int* nk = next + key;
+            const int pos = *nk + __popcll(same & ((1ull << lane) - 1ull));
+            order[pos] = t;
+            sorted_key[pos] = key;
+            if ((same & ((1ull << lane) - 1ull)) == 0) *nk = pos + __popcll(same);
         }
     }
 }
@@ -702,7 +708,7 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     CM3P_NC_SWITCH(H, CM3P_LN_BWD)
 #undef CM3P_LN_BWD
     CM3P_LAUNCH_CHECK();
-    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
+    colsum_kernel<<<(H + 31) / 32, 1024, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -758,7 +764,7 @@ int cm3p_embed_ln_bwd(const float* dy, const int64_t* ids, const void* table, in
 #undef CM3P_EMB_BWD
 #undef CM3P_EMB_BWD_NC
     CM3P_LAUNCH_CHECK();
-    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
+    colsum_kernel<<<(H + 31) / 32, 1024, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
@@ -796,7 +802,7 @@ int cm3p_embed_ln_bwd_sorted(const float* dy, const int64_t* ids, const int64_t*
     CM3P_NC_SWITCH(H, CM3P_EMB_SUM_NC)
 #undef CM3P_EMB_SUM_NC
     CM3P_LAUNCH_CHECK();
-    colsum_kernel<<<(H + 31) / 32, 256, 0, s>>>(dw_partial, dw, grid, H);
+    colsum_kernel<<<(H + 31) / 32, 1024, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

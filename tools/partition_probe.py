@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Can the weight-gradient GEMMs of the backward chain run on a FIXED slice of every XCD's CUs while the chain itself (input-gradient
+GEMMs, attention backward, LayerNorm / GeGLU backward) runs on the rest?  The chain's streaming kernels are HBM-bound and leave the
+matrix cores idle; a weight-gradient GEMM that owns k CUs per XCD would use that time.
+
+r03's `overlap_cumask.py` masked CUs by `i % 16`, which (mask bit i = CU i // 8 of XCD i % 8) thinned two XCDs only; the dispatcher
+deals workgroups to XCDs round-robin, so those XCDs became the whole chip's tail.  Here every XCD gives up the same k CUs.
+
+One "layer" = the kernels of _EncoderLayerFn.backward at C2 shapes (T = 32 x 4096, H 768, I 1152), sliding-window or global attention.
+Timed: `--layers` layers back to back, (a) everything on one stream on the whole chip, (b) chain on the big mask, weight gradients on the
+small mask (each waits for the event of the kernel that produced its operand; the two streams join only at the end).
+
+    python tools/partition_probe.py [--layers 6] [--iters 5] [--k 4 6 8]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cm3p_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+hip = ctypes.CDLL("libamdhip64.so")
+
+
+def masked_stream(pred):
+    words = (ctypes.c_uint32 * 8)()
+    n = 0
+    for i in range(256):
+        if pred(i):
+            words[i // 32] |= 1 << (i % 32)
+            n += 1
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(h.value), n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--k", type=int, nargs="+", default=[4, 6, 8])
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--S", type=int, default=4096)
+    args = ap.parse_args()
+    B, S, H, I, nh = args.B, args.S, 768, 1152, 12
+    T = B * S
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    wq = lambda n, k: (torch.randn(n, k, device=DEV, generator=g) * 0.02).to(torch.bfloat16)
+    Wqkv, Wo, Wi, Wo2 = wq(3 * H, H), wq(H, H), wq(2 * I, H), wq(H, I)
+    Wqkv_t, Wo_t, Wi_t, Wo2_t = (w.t().contiguous() for w in (Wqkv, Wo, Wi, Wo2))
+    x = torch.randn(T, H, device=DEV, generator=g)
+    ones = torch.ones(H, device=DEV)
+    _, xn, mean, rstd = K.layernorm_fwd(x, ones, 1e-5, False, True)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=DEV).float() / 64))
+    ang = torch.arange(S, device=DEV).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    qkv = K.qkv_linear_rope(xn, Wqkv, cos, sin, S, False, q_scale=K.SOFTMAX_Q_SCALE)
+    acts = {}
+    for name, window in (("local", 64), ("global", -1)):
+        o, lse = K.attn_fwd(qkv, None, B, S, nh, window, 0.125, prescaled=True)
+        acts[name] = (window, o, lse)
+    h = rnd(T, 2 * I)
+    gact = K.geglu_fwd(h)
+    gx32 = torch.randn(T, H, device=DEV, generator=g)
+    gx16 = K.cast_bf16(gx32)
+    torch.cuda.synchronize()
+    main_s = torch.cuda.current_stream()
+
+    def layer(kind, side, chain_done):
+        """Issues one layer's backward on the current stream; weight gradients through side(fn) after the event of their operand."""
+        window, o, lse = acts[kind]
+        dg = K.linear_dgrad(gx16, Wo2, Wo2_t)
+        side(lambda: K.linear_wgrad(gx16, gact))
+        dh = K.geglu_bwd(dg, h)
+        dxn2 = K.linear_dgrad(dh, Wi, Wi_t)
+        side(lambda: K.linear_wgrad(dh, xn))
+        g32, g16, _ = K.layernorm_bwd(dxn2, x, ones, mean, rstd, gx32, True, inplace=False)
+        do = K.linear_dgrad(g16, Wo, Wo_t)
+        side(lambda: K.linear_wgrad(g16, o))
+        dqkv = K.attn_bwd(qkv, o, do, lse, None, B, S, nh, window, 0.125, (cos, sin), False, prescaled=True)
+        side(lambda: K.linear_wgrad(dqkv, xn))
+        dxn = K.linear_dgrad(dqkv, Wqkv, Wqkv_t)
+        K.layernorm_bwd(dxn, x, ones, mean, rstd, g32, True, inplace=False)
+        chain_done()
+
+    kinds = ["global" if i % 3 == 0 else "local" for i in range(args.layers)]
+
+    def serial():
+        for kd in kinds:
+            layer(kd, lambda fn: fn(), lambda: None)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return min(ts), sum(ts) / len(ts)
+
+    for k in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
+        os.environ.pop(k, None)
+    t_ser = timed(serial)
+    print(f"{args.layers} layers, one stream, whole chip: min {t_ser[0]:.3f} ms  mean {t_ser[1]:.3f} ms", flush=True)
+
+    for k in args.k:
+        s_small, n_small = masked_stream(lambda i: (i // 8) >= 32 - k)
+        s_big, n_big = masked_stream(lambda i: (i // 8) < 32 - k)
+
+        def grid(n):
+            os.environ["CM3P_G8P_GRID"] = str(n)
+            os.environ["CM3P_LN_BWD_CAP"] = str(n * 4)
+
+        def split():
+            s_big.wait_stream(main_s)
+            s_small.wait_stream(main_s)
+            with torch.cuda.stream(s_big):
+                def side(fn):
+                    ev = torch.cuda.Event()
+                    ev.record(s_big)
+                    grid(n_small)
+                    with torch.cuda.stream(s_small):
+                        s_small.wait_event(ev)
+                        fn()
+                    grid(n_big)
+                grid(n_big)
+                for kd in kinds:
+                    layer(kd, side, lambda: None)
+            main_s.wait_stream(s_big)
+            main_s.wait_stream(s_small)
+
+        def chain_only():
+            s_big.wait_stream(main_s)
+            with torch.cuda.stream(s_big):
+                grid(n_big)
+                for kd in kinds:
+                    layer(kd, lambda fn: None, lambda: None)
+            main_s.wait_stream(s_big)
+
+        def side_only():
+            s_small.wait_stream(main_s)
+            with torch.cuda.stream(s_small):
+                grid(n_small)
+                for kd in kinds:
+                    o = acts[kd][1]
+                    K.linear_wgrad(gx16, gact), K.linear_wgrad(h, xn), K.linear_wgrad(gx16, o), K.linear_wgrad(qkv, xn)
+            main_s.wait_stream(s_small)
+
+        t_c, t_s, t_p = timed(chain_only), timed(side_only), timed(split)
+        print(f"k = {k}: chain on {n_big} CUs alone {t_c[0]:.3f} ms, weight gradients on {n_small} CUs alone {t_s[0]:.3f} ms, "
+              f"both at once min {t_p[0]:.3f} mean {t_p[1]:.3f} ms  (one stream, whole chip: {t_ser[0]:.3f})", flush=True)
+        for kk in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
+            os.environ.pop(kk, None)
+
+
+if __name__ == "__main__":
+    main()
