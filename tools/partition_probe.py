@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--k", type=int, nargs="+", default=[4, 6, 8])
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--S", type=int, default=4096)
+    ap.add_argument("--only", choices=["serial", "chain", "side", "split"], default=None,
+                    help="run just this arrangement (for a rocprofv3 --kernel-trace --stats pass per arrangement)")
     args = ap.parse_args()
     B, S, H, I, nh = args.B, args.S, 768, 1152, 12
     T = B * S
@@ -72,22 +74,45 @@ def main():
     torch.cuda.synchronize()
     main_s = torch.cuda.current_stream()
 
+    marks = []  # (name, start event, end event) of every kernel call of the pass being timed (events on the stream it ran on)
+
+    def tm(name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        marks.append((name, e0, e1))
+        return r
+
     def layer(kind, side, chain_done):
         """Issues one layer's backward on the current stream; weight gradients through side(fn) after the event of their operand."""
         window, o, lse = acts[kind]
-        dg = K.linear_dgrad(gx16, Wo2, Wo2_t)
-        side(lambda: K.linear_wgrad(gx16, gact))
-        dh = K.geglu_bwd(dg, h)
-        dxn2 = K.linear_dgrad(dh, Wi, Wi_t)
-        side(lambda: K.linear_wgrad(dh, xn))
-        g32, g16, _ = K.layernorm_bwd(dxn2, x, ones, mean, rstd, gx32, True, inplace=False)
-        do = K.linear_dgrad(g16, Wo, Wo_t)
-        side(lambda: K.linear_wgrad(g16, o))
-        dqkv = K.attn_bwd(qkv, o, do, lse, None, B, S, nh, window, 0.125, (cos, sin), False, prescaled=True)
-        side(lambda: K.linear_wgrad(dqkv, xn))
-        dxn = K.linear_dgrad(dqkv, Wqkv, Wqkv_t)
-        K.layernorm_bwd(dxn, x, ones, mean, rstd, g32, True, inplace=False)
+        dg = tm("dgrad Wo2", lambda: K.linear_dgrad(gx16, Wo2, Wo2_t))
+        side(lambda: tm("wgrad Wo2", lambda: K.linear_wgrad(gx16, gact)))
+        dh = tm("geglu bwd", lambda: K.geglu_bwd(dg, h))
+        dxn2 = tm("dgrad Wi", lambda: K.linear_dgrad(dh, Wi, Wi_t))
+        side(lambda: tm("wgrad Wi", lambda: K.linear_wgrad(dh, xn)))
+        g32, g16, _ = tm("LN bwd", lambda: K.layernorm_bwd(dxn2, x, ones, mean, rstd, gx32, True, inplace=False))
+        do = tm("dgrad Wo", lambda: K.linear_dgrad(g16, Wo, Wo_t))
+        side(lambda: tm("wgrad Wo", lambda: K.linear_wgrad(g16, o)))
+        dqkv = tm("attn bwd " + kind, lambda: K.attn_bwd(qkv, o, do, lse, None, B, S, nh, window, 0.125, (cos, sin), False, prescaled=True))
+        side(lambda: tm("wgrad Wqkv", lambda: K.linear_wgrad(dqkv, xn)))
+        dxn = tm("dgrad Wqkv", lambda: K.linear_dgrad(dqkv, Wqkv, Wqkv_t))
+        tm("LN bwd", lambda: K.layernorm_bwd(dxn, x, ones, mean, rstd, g32, True, inplace=False))
         chain_done()
+
+    def per_kernel(fn):
+        """One more pass of fn; -> {name: mean ms per call} from the events around every call."""
+        marks.clear()
+        fn()
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in marks:
+            a = acc.setdefault(name, [0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+        marks.clear()
+        return {k: v[0] / v[1] for k, v in acc.items()}
 
     kinds = ["global" if i % 3 == 0 else "local" for i in range(args.layers)]
 
@@ -110,8 +135,11 @@ def main():
 
     for k in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
         os.environ.pop(k, None)
-    t_ser = timed(serial)
+    t_ser = timed(serial) if args.only in (None, "serial") else (float("nan"), float("nan"))
+    if args.only == "serial":
+        return
     print(f"{args.layers} layers, one stream, whole chip: min {t_ser[0]:.3f} ms  mean {t_ser[1]:.3f} ms", flush=True)
+    pk_ser = per_kernel(serial)
 
     for k in args.k:
         s_small, n_small = masked_stream(lambda i: (i // 8) >= 32 - k)
@@ -156,9 +184,16 @@ def main():
                     K.linear_wgrad(gx16, gact), K.linear_wgrad(h, xn), K.linear_wgrad(gx16, o), K.linear_wgrad(qkv, xn)
             main_s.wait_stream(s_small)
 
-        t_c, t_s, t_p = timed(chain_only), timed(side_only), timed(split)
+        nan = (float("nan"), float("nan"))
+        t_c = timed(chain_only) if args.only in (None, "chain") else nan
+        t_s = timed(side_only) if args.only in (None, "side") else nan
+        t_p = timed(split) if args.only in (None, "split") else nan
         print(f"k = {k}: chain on {n_big} CUs alone {t_c[0]:.3f} ms, weight gradients on {n_small} CUs alone {t_s[0]:.3f} ms, "
               f"both at once min {t_p[0]:.3f} mean {t_p[1]:.3f} ms  (one stream, whole chip: {t_ser[0]:.3f})", flush=True)
+        pk_c, pk_p = per_kernel(chain_only), per_kernel(split)
+        print(f"    {'ms per call':14s} {'whole chip':>10s} {'big mask':>10s} {'beside / as wgrad':>18s}")
+        for name in pk_ser:
+            print(f"    {name:14s} {pk_ser[name]:10.3f} {pk_c.get(name, float('nan')):10.3f} {pk_p.get(name, float('nan')):18.3f}", flush=True)
         for kk in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
             os.environ.pop(kk, None)
 
