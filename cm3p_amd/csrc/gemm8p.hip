@@ -616,7 +616,7 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
     int want = num_cu;
     if (const char* e = getenv("CM3P_G8P_GRID")) {  // development switch: leave CUs to a kernel on another stream (tools/overlap_ab.py)
         const int g = atoi(e);
-        if (g > 0 && g < want) want = g;
+        if (g > 0) want = g;  // (more workgroups than CUs: the surplus is dispatched as CUs come free - tools/blocker_probe.py)
     }
     const dim3 grid(total < want ? total : want);
 #define CM3P_G8P(E)                                                                                                               \
