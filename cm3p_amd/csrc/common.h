@@ -162,6 +162,57 @@ static inline bool cm3p_aligned16(const void* p) { return (reinterpret_cast<uint
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
+// ---- exact-erf GELU (TF ACT2FN["gelu"], approximate="none"), two values per call so that the polynomial runs on v_pk_fma_f32 ----------
+// Phi(x) = 1/2 erfc(-x / sqrt 2) with erfc(z) = t exp(-z^2 + P(t)), t = 1 / (1 + z / 2), z >= 0 (the Chebyshev fit of Numerical Recipes'
+// erfcc: fractional error < 1.2e-7 in exact arithmetic, 3.3e-6 as evaluated here in fp32 over EVERY bf16 input, relative also in the negative
+// tail where 1 + erf(x / sqrt 2) cancels to zero).  16 VALU instructions per value (three of them v_rcp / v_exp) against 45 with the device
+// library's erff + expf; of the 65280 finite bf16 inputs, gelu rounds to a different bf16 than the exact value for 64 (197 with
+// 0.5 x (1 + erff)).  One definition for every GELU of the library (GeGLU forward / backward, the fused Wi + GeGLU epilogue, the audio
+// encoder's bias + GELU): same source, same bits.  Q(t) = log2(e) P(t).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_q_poly(f32x2 t) {
+    f32x2 q = t * 0.24651730060577393f + (-1.1861149072647095f);
+    q = q * t + 2.147474527359009f;
+    q = q * t + (-1.6377531290054321f);
+    q = q * t + 0.40232157707214355f;
+    q = q * t + (-0.2687568664550781f);
+    q = q * t + 0.1396300494670868f;
+    q = q * t + 0.5397006273269653f;
+    q = q * t + 1.4427292346954346f;
+    q = q * t + (-1.8257482051849365f);
+    return q;
+}
+__device__ __forceinline__ f32x2 gelu_t(f32x2 x) {
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 w = ax * 0.35355339059327373f + 1.0f;  // 1 + z / 2, z = |x| / sqrt 2
+    return f32x2{__builtin_amdgcn_rcpf(w.x), __builtin_amdgcn_rcpf(w.y)};
+}
+// Phi(x) and the standard normal density (the backward needs both: gelu'(x) = Phi(x) + x phi(x))
+__device__ __forceinline__ void gelu_cdf_pdf2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    const f32x2 t = gelu_t(x);
+    const f32x2 q = gelu_q_poly(t);
+    const f32x2 u = x * x * (-0.72134752044448170f);  // -x^2 / 2 in log2 units
+    const f32x2 eu = {__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+    const f32x2 eq = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const f32x2 h = t * eu * eq * 0.5f;  // erfc(|x| / sqrt 2) / 2
+    cdf.x = x.x < 0.f ? h.x : 1.0f - h.x;
+    cdf.y = x.y < 0.f ? h.y : 1.0f - h.y;
+    pdf = eu * 0.39894228040143267794f;
+}
+// gelu(x) = x Phi(x); the forward needs one exponential per value
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 t = gelu_t(x);
+    const f32x2 e = x * x * (-0.72134752044448170f) + gelu_q_poly(t);
+    const f32x2 h = t * f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * 0.5f;
+    const f32x2 cdf = {x.x < 0.f ? h.x : 1.0f - h.x, x.y < 0.f ? h.y : 1.0f - h.y};
+    return x * cdf;
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
+    f32x2 cdf, pdf;
+    gelu_cdf_pdf2(x, cdf, pdf);
+    return x * pdf + cdf;
+}
+
 // packs two floats into one dword of two bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserving)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2 v = {(__bf16)lo, (__bf16)hi};

@@ -16,11 +16,8 @@ inline int cv_grid(int64_t items) {
     return (int)blocks;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
+// (the GELU: gelu_erf2 / gelu_erf_grad2 in common.h, two values per call)
+__device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_erf_grad2(f32x2{x, x}).x; }
 
 // x: [B, C, T_in] fp32 (channel-major, the model input) -> patches [B*T_out, C*3] bf16
 __global__ __launch_bounds__(256) void im2col_cm_kernel(const float* __restrict__ x, uint16_t* __restrict__ p, int B, int C,
@@ -87,7 +84,8 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const float* __restr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int col = (int)(i % c4) * 4;
         const f32x4 v = reinterpret_cast<const f32x4*>(z)[i] + *reinterpret_cast<const f32x4*>(bias + col);
-        const f32x4 g = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+        const f32x2 g01 = gelu_erf2(f32x2{v.x, v.y}), g23 = gelu_erf2(f32x2{v.z, v.w});
+        const f32x4 g = {g01.x, g01.y, g23.x, g23.y};
         if (a32) reinterpret_cast<f32x4*>(a32)[i] = g;
         if (a16) reinterpret_cast<uint2*>(a16)[i] = uint2{pack_bf16x2(g.x, g.y), pack_bf16x2(g.z, g.w)};
     }
@@ -141,9 +139,12 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_vec_kernel(const void* __re
     auto one = [&](int64_t i, f32x4 g, f32x4 zz, int k) {
         uint16_t qb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qb[j] = f32_to_bf16_bits(g[j] * gelu_erf_grad(zz[j] + bv[k][j]));
+        for (int j = 0; j < 4; j += 2) {
+            const f32x2 gr = gelu_erf_grad2(f32x2{zz[j] + bv[k][j], zz[j + 1] + bv[k][j + 1]});
+            qb[j] = f32_to_bf16_bits(g[j] * gr.x);
+            qb[j + 1] = f32_to_bf16_bits(g[j + 1] * gr.y);
             acc[k][j] += bf16_bits_to_f32(qb[j]);  // the bias gradient sums exactly what the GEMMs downstream will see
+            acc[k][j + 1] += bf16_bits_to_f32(qb[j + 1]);
         }
         *reinterpret_cast<uint2*>(dz + i) = uint2{(uint32_t)qb[0] | ((uint32_t)qb[1] << 16), (uint32_t)qb[2] | ((uint32_t)qb[3] << 16)};
     };

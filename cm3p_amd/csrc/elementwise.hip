@@ -16,13 +16,7 @@ inline int ew_grid(int64_t items, int per_block = 256) {
     return (int)blocks;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
-
+// (the GELU itself: gelu_erf2 / gelu_cdf_pdf2 in common.h)
 __device__ __forceinline__ void unpack8(const uint4 w, float (&f)[8]) {
     f[0] = bf16lo(w.x); f[1] = bf16hi(w.x); f[2] = bf16lo(w.y); f[3] = bf16hi(w.y);
     f[4] = bf16lo(w.z); f[5] = bf16hi(w.z); f[6] = bf16lo(w.w); f[7] = bf16hi(w.w);
@@ -187,35 +181,59 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(uint16_t* __restrict__ 
 
 // ---- GeGLU / GELU -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ h, uint16_t* __restrict__ g, int64_t T, int I) {
+    // item i = (row t, 16-byte chunk c) with i = t * c8 + c, walked with the grid's stride; the (t, c) pair is advanced by the
+    // stride's quotient and remainder instead of a 64-bit division per item
     const int c8 = I / 8;
-    const int64_t total = T * c8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t t = i / c8;
-        const int c = (int)(i % c8);
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t dq = stride / c8;
+    const int dr = (int)(stride % c8);
+    int64_t t = i0 / c8;
+    int c = (int)(i0 % c8);
+    for (; t < T; t += dq, c += dr) {
+        if (c >= c8) {
+            c -= c8;
+            if (++t >= T) break;
+        }
         float a[8], b[8], y[8];
         unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
         unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = gelu_erf(a[j]) * b[j];
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = gelu_erf2(f32x2{a[j], a[j + 1]});
+            y[j] = gl.x * b[j];
+            y[j + 1] = gl.y * b[j + 1];
+        }
         gstore16<(CM3P_NT & 16) != 0>(g + t * I + c * 8, pack8(y));
     }
 }
 
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ dg, const uint16_t* __restrict__ h,
                                                         uint16_t* __restrict__ dh, int64_t T, int I) {
-    const int c8 = I / 8;
-    const int64_t total = T * c8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t t = i / c8;
-        const int c = (int)(i % c8);
+    const int c8 = I / 8;  // (item walk: see geglu_fwd_kernel)
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t dq = stride / c8;
+    const int dr = (int)(stride % c8);
+    int64_t t = i0 / c8;
+    int c = (int)(i0 % c8);
+    for (; t < T; t += dq, c += dr) {
+        if (c >= c8) {
+            c -= c8;
+            if (++t >= T) break;
+        }
         float a[8], b[8], d[8], da[8], db[8];
         unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
         unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
         unpack8(gload16<(CM3P_NT & 128) != 0>(dg + t * I + c * 8), d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            da[j] = d[j] * b[j] * gelu_erf_grad(a[j]);
-            db[j] = d[j] * gelu_erf(a[j]);
+        for (int j = 0; j < 8; j += 2) {  // gelu'(a) = Phi(a) + a phi(a), gelu(a) = a Phi(a): one Phi for both
+            const f32x2 av = {a[j], a[j + 1]};
+            f32x2 cdf, pdf;
+            gelu_cdf_pdf2(av, cdf, pdf);
+            const f32x2 gr = av * pdf + cdf, gl = av * cdf;
+            da[j] = d[j] * b[j] * gr.x;
+            da[j + 1] = d[j + 1] * b[j + 1] * gr.y;
+            db[j] = d[j] * gl.x;
+            db[j + 1] = d[j + 1] * gl.y;
         }
         gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + c * 8, pack8(da));
         gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + I + c * 8, pack8(db));
@@ -227,7 +245,11 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const uint16_t* __restric
         float a[8], o[8];
         unpack8(reinterpret_cast<const uint4*>(x)[i], a);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = gelu_erf(a[j]);
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gl = gelu_erf2(f32x2{a[j], a[j + 1]});
+            o[j] = gl.x;
+            o[j + 1] = gl.y;
+        }
         reinterpret_cast<uint4*>(y)[i] = pack8(o);
     }
 }
@@ -239,7 +261,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restric
         unpack8(reinterpret_cast<const uint4*>(x)[i], a);
         unpack8(reinterpret_cast<const uint4*>(dy)[i], d);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = d[j] * gelu_erf_grad(a[j]);
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 gr = gelu_erf_grad2(f32x2{a[j], a[j + 1]});
+            o[j] = d[j] * gr.x;
+            o[j + 1] = d[j + 1] * gr.y;
+        }
         reinterpret_cast<uint4*>(dx)[i] = pack8(o);
     }
 }

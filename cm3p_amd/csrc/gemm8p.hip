@@ -65,7 +65,6 @@ __device__ __forceinline__ void glds_s(uint32_t voff, const char* sbase, uint32_
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // (HIP's uint4 is a struct: arrays of it land in scratch)
 
-__device__ __forceinline__ float gelu_erf8p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }  // (elementwise.hip's, to the bit)
 
 #if CM3P_G8P_ABL & 1
 #define G8P_GLOBAL(stmt) asm volatile("" ::: "memory")
@@ -467,8 +466,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                 G8P_LANE_XCHG_FENCE();
                 u32x4 y;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    y[t] = pack_bf16x2(gelu_erf8p(bf16lo(xh[t])) * bf16lo(xg[t]), gelu_erf8p(bf16hi(xh[t])) * bf16hi(xg[t]));
+                for (int t = 0; t < 4; ++t) {  // (gelu_erf2: common.h, the function cm3p_geglu_fwd evaluates - same bits)
+                    const f32x2 gl = gelu_erf2(f32x2{bf16lo(xh[t]), bf16hi(xh[t])});
+                    y[t] = pack_bf16x2(gl.x * bf16lo(xg[t]), gl.y * bf16hi(xg[t]));
+                }
                 if (FULL || (mw + i4 * 16 + row < M && nw + dc * 8 < N))
                     G8P_GLOBAL(gstore16<(CM3P_NT & 1) != 0>(Cb + (uint32_t)(i4 * 16 + row) * ldcb + dc * 16, y));
                 if constexpr (CM3P_G8P_ABL & 1) asm volatile("" ::"v"(y));
