@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
     constexpr int QW = 32 * QSUB;  // queries per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
     int qblk, head, b;
-    decode_block((Smax + 4 * QW - 1) / (4 * QW), nh, qblk, head, b);
+    if (BAND) decode_block_band((Smax + 4 * QW - 1) / (4 * QW), nh, qblk, head, b);
+    else decode_block((Smax + 4 * QW - 1) / (4 * QW), nh, qblk, head, b);
     const int Q0 = qblk * (4 * QW);
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
                                                              const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int qblk, head, b;
-    decode_block((Smax + 127) / 128, nh, qblk, head, b);
+    if (window >= 0) decode_block_band((Smax + 127) / 128, nh, qblk, head, b);
+    else decode_block((Smax + 127) / 128, nh, qblk, head, b);
     band_dq_block<PRE, MASK>(smem, qblk, head, b, qkv, d_o, o_rows, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin,
                                     pos_batch_stride, vl);
 }
@@ -647,7 +649,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
                                                               const float* __restrict__ rope_sin, int64_t pos_batch_stride, VarLen vl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int kblk, head, b;
-    decode_block((Smax + 127) / 128, nh, kblk, head, b);
+    if (window >= 0) decode_block_band((Smax + 127) / 128, nh, kblk, head, b);
+    else decode_block((Smax + 127) / 128, nh, kblk, head, b);
     band_dkv_block<PRE>(smem, kblk, head, b, qkv, d_o, lse, delta, dqkv, kmask, Smax, nh, window, scale, rope_cos, rope_sin, pos_batch_stride, vl);
 }
 

@@ -37,6 +37,25 @@ __device__ __forceinline__ void decode_block(int nblk, int nh, int& blk, int& he
     b = bh / nh;
 }
 
+// The same grid for the SLIDING-WINDOW kernels: head fastest, then the block along the sequence.  A band workgroup reads each row
+// of its head once (plus a halo), 128 bytes out of a 4608-byte token row; with the twelve heads of a row block on neighbouring
+// workgroups the whole token row is consumed while its DRAM page is open, and a row block's neighbours (the halo) are still on the
+// same XCD.  Speed only (r04: see DESIGN section 4); any order is correct.
+#ifndef CM3P_BAND_ORDER
+#define CM3P_BAND_ORDER 1  // 0: the global kernels' order (A/B builds)
+#endif
+__device__ __forceinline__ void decode_block_band(int nblk, int nh, int& blk, int& head, int& b) {
+    if constexpr (CM3P_BAND_ORDER == 0) {
+        decode_block(nblk, nh, blk, head, b);
+    } else {
+        const int logical = xcd_remap(blockIdx.x, gridDim.x);
+        head = logical % nh;
+        const int rb = logical / nh;
+        blk = rb % nblk;
+        b = rb / nblk;
+    }
+}
+
 // Unpadded ("varlen") batches: sequences are packed back to back, sequence b occupies rows cu[b] .. cu[b+1]-1 of the
 // [total, ...] tensors (the layout the reference's flash_attention_2 path builds with _unpad_cm3p_input,
 // ref:cm3p/modeling_cm3p.py:65-134) and the per-row statistics are [nh, total].  cu == nullptr: padded [B, S, ...] tensors.
