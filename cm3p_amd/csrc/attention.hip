@@ -285,6 +285,23 @@ __global__ __launch_bounds__(256, QSUB == 1 ? 2 : 1) void attn_fwd_kernel(const 
 // same geometry as the forward.  LDS per ring slot: K image (row + transposed reads) + V image + one validity dword per key; tiles
 // arrive by LDS-DMA (TileDma, attn_common.h), the result leaves as whole rows (store_rows32).
 // ---------------------------------------------------------------------------------------------------------------
+// Phase timestamps of the dQ sweep (trace builds only: -DCM3P_BAND_TRACE=1, tools/band_trace.py): thread 0 of every workgroup writes the
+// 100 MHz wall clock at entry (0), after the prologue's requests (1), when tile i is ready (2 + 2 i) and swept (3 + 2 i), after the
+// last barrier (14) and after the stores are issued (15).
+#ifndef CM3P_BAND_TRACE
+#define CM3P_BAND_TRACE 0
+#endif
+#if CM3P_BAND_TRACE
+__device__ unsigned long long* g_band_trace = nullptr;
+#define BAND_T(k)                                                                                          \
+    do {                                                                                                   \
+        if (g_band_trace && threadIdx.x == 0) g_band_trace[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define BAND_T(k) \
+    do {          \
+    } while (0)
+#endif
 constexpr int kDqStage = 2 * 8192 + 256;  // K image, V image, one validity dword per key
 constexpr int kDqSlots = 4;               // LDS-DMA ring: tile t+3 is requested while tile t is consumed
 
@@ -301,6 +318,7 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
     const SeqView sv(vl, b, head, Smax, nh);
     const int S = sv.S;
     if (Q0 >= S) return;
+    BAND_T(0);
     const int q0 = Q0 + wid * 32;
     const int64_t ld = (int64_t)3 * nh * 64;
     const uint16_t* qbase = qkv + sv.row0 * ld + head * 64;
@@ -385,9 +403,11 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
     }
 
 
+    BAND_T(1);
     for (int t = t_lo; t <= t_hi; ++t) {
         const char* st = smem + ((t - t_lo) & (kDqSlots - 1)) * kDqStage;
         dma_wait_barrier(ND * min(t_hi - t, 2));  // tile t has landed in every wave; the slot of tile t-1 is free
+        BAND_T(2 + 2 * (t - t_lo));
         if (t + 3 <= t_hi) dma_tile(t + 3);
         const int key0 = t * 64;
         if (wave_live && key0 <= whi && key0 + 63 >= wlo) {
@@ -424,6 +444,7 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
                 }
             }
         }
+        BAND_T(3 + 2 * (t - t_lo));
     }
 
     if (rope_cos) {  // backward of apply_rotary_pos_emb (the transposed rotation): dims d / d+32 are the lane's two accumulator blocks
@@ -437,7 +458,9 @@ __device__ __forceinline__ void band_dq_block(char* smem, int qblk, int head, in
             }
     }
     lds_only_barrier();  // every wave is done with the ring: its slots become the waves' transposition buffers
+    BAND_T(14);
     store_rows32(smem + 4608 * wid, dq[0], dq[1], scale, dqkv + (sv.row0 + q0) * ld + head * 64, ld, S - q0, lane);
+    BAND_T(15);
 }
 
 template <bool PRE, bool MASK>
@@ -841,6 +864,12 @@ int cm3p_attn_probs(const void* qkv, const float* lse, const uint8_t* key_mask, 
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
 int cm3p_ablation_flags_attention() { return (CM3P_BABL); }
+#if CM3P_BAND_TRACE
+extern "C" int cm3p_debug_set_band_trace(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_band_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 #if CM3P_DMA_AUDIT
 int cm3p_audit_set_attention(void* buf) { return cm3p_audit_set_local(buf); }
 #endif
