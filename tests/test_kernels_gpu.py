@@ -362,6 +362,46 @@ def test_geglu_and_gelu(K):
                   1e-5, 8e-3, "gelu bwd")
 
 
+def test_gelu_on_every_finite_bf16_input_against_float64(K):
+    """The library's one GELU (csrc/common.h: Phi through the erfcc fit on packed FMAs) on ALL 65280 finite bf16 inputs: the bf16 it
+    returns is the correctly rounded fp64 value or its neighbour, also far in the negative tail where 0.5 x (1 + erf) cancels; and the
+    derivative gelu'(x) = Phi(x) + x phi(x) likewise."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = (bits << 16).view(torch.float32)
+    x = x[torch.isfinite(x)].to(torch.bfloat16)
+    assert x.numel() == 65280
+    n = x.numel()
+    pad = (-n) % 8
+    xp = torch.cat([x, torch.zeros(pad, dtype=torch.bfloat16)]).to(DEV)
+    y = K.gelu_fwd(xp)[:n].double().cpu()
+    dy = K.gelu_bwd(torch.ones_like(xp), xp)[:n].double().cpu()
+    xd = x.double()
+    cdf = 0.5 * torch.special.erfc(-xd / 2 ** 0.5)
+    ref = xd * cdf
+    dref = cdf + xd * torch.exp(-0.5 * xd * xd) / (2 * torch.pi) ** 0.5
+    big = xd.abs() < 1e30  # (x * Phi(x) overflows bf16 beyond that: inf either way)
+    # one bf16 ulp of the exact value (2^-8 relative covers round-to-nearest of a neighbour), plus denormal slack
+    assert ((y - ref).abs()[big] <= ref.abs()[big] * 2.0 ** -8 + 1e-37).all(), ((y - ref).abs() / ref.abs().clamp_min(1e-37))[big].max()
+    assert ((dy - dref).abs()[big] <= dref.abs()[big] * 2.0 ** -8 + 1e-6).all()
+    same = (y.to(torch.bfloat16) == ref.to(torch.bfloat16))[big].float().mean().item()
+    assert same > 0.998, same  # (measured: 64 of 65280 round to the neighbouring bf16)
+
+
+def test_ring_gemm_with_more_workgroups_than_cus_is_the_same_gemm(K, monkeypatch):
+    """CM3P_G8P_GRID above the CU count (the switch for sharing the chip with a communication kernel): the surplus
+    workgroups walk the same work items - bit-identical results."""
+    g = torch.Generator().manual_seed(31)
+    M, N, Kd = 17928, 768, 256  # 71 x 3 tiles of 256 x 256 (the ring kernel's threshold is 200), a ragged last row tile
+    a, w = _bf(torch.randn(M, Kd, generator=g)).to(DEV), _bf(torch.randn(N, Kd, generator=g) * 0.1).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    monkeypatch.delenv("CM3P_G8P_GRID", raising=False)
+    want16, want32 = K.linear_fwd(a, w), K.linear_fwd(a, w, resid=r)
+    for grid in ("64", "300", "1024"):
+        monkeypatch.setenv("CM3P_G8P_GRID", grid)
+        assert torch.equal(K.linear_fwd(a, w), want16), grid
+        assert torch.equal(K.linear_fwd(a, w, resid=r), want32), grid
+
+
 @pytest.mark.parametrize("cls,use_mask", [(True, True), (False, True), (False, False)])
 def test_pooling(K, cls, use_mask):
     from oracle import cm3p_oracle as O
