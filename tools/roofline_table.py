@@ -38,7 +38,7 @@ def main():
         tb = traffic.get(k)
         b = busy.get(k, {})
         print(f"| `{k}` | {int(r['Calls']) / steps:.0f} | {us:.1f} | {ms:.2f} | {tb / 1e6:.0f} | {tb / (us * 1e-6) / 1e12:.2f} | "
-              f"{100 * b.get('mfma_util', 0):.1f} % | {b.get('clock_ghz', float('nan')):.2f} |" if tb else
+              + (f"{100 * b['mfma_util']:.1f} % | {b['clock_ghz']:.2f} |" if b.get("mfma_util") else "- | - |") if tb else
               f"| `{k}` | {int(r['Calls']) / steps:.0f} | {us:.1f} | {ms:.2f} | - | - | - | - |")
 
 
