@@ -211,6 +211,19 @@ def optimizer_leg(model, steps: int = 3):
     }
 
 
+def hbm_rows(bracketed_step: dict) -> list:
+    """The HBM-bound tags of one fully bracketed step: achieved GB/s on algorithmic bytes, as a fraction of the 8 TB/s of MI355X_MICROARCH.md."""
+    from cm3p_amd import _lib
+
+    rows = []
+    for tag, (n, ms, work) in sorted(bracketed_step.items(), key=lambda kv: -kv[1][1]):
+        if tag in _lib.HBM_BOUND_TAGS and work and ms > 0 and ms >= 0.5:
+            gbs = work / (ms * 1e-3) / 1e9
+            rows.append({"kernel": tag, "launches": n, "ms_per_step": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    return rows
+
+
 def roofline_object(tag: str, timed_launches, bracketed_step: dict, workload: str) -> dict:
     """The `roofline` object of one workload: `timed_launches` = (launches, total ms, total algorithmic work) of the dominant tag as timed
     with HIP events inside the timed steps, `bracketed_step` = every tag of one fully bracketed step (for the kernel's share)."""
@@ -484,6 +497,9 @@ def main():
             result["roofline"] = roofline_object(dom_tag, prof[dom_tag], prof_all, args.workload)
             result["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])[:12]}
             result["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
+            # the streaming kernels against the HBM roofline (north star: "rocprof HBM GB/s ... vs gfx950 peak"): algorithmic bytes per launch
+            # (what one pass must read and write) / the launch's duration in that bracketed step, both towers' launches averaged
+            result["hbm_kernels"] = hbm_rows(prof_all)
         if comm is not None:
             result["comm"] = comm
         if replicas is not None:
@@ -515,6 +531,7 @@ def main():
         if prof4.get(dom4):
             result["secondary"]["roofline"] = roofline_object(dom4, prof4[dom4], prof4_all, "c4")
             result["secondary"]["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof4_all.items(), key=lambda kv: -kv[1][1])[:12]}
+            result["secondary"]["hbm_kernels"] = hbm_rows(prof4_all)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not w.get("mlm"):  # (the oracle's timed leg covers the BASELINE workloads)
             del batch
