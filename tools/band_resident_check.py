@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Sliding-window backward, resident dQ sweep against the per-block kernel: run twice (CM3P_BAND_RESIDENT unset / =0) with --save, then --compare.
-    python tools/band_resident_check.py --save /tmp/a.pt; CM3P_BAND_RESIDENT=0 python tools/band_resident_check.py --save /tmp/b.pt; python tools/band_resident_check.py --compare /tmp/a.pt /tmp/b.pt"""
+"""Sliding-window backward of two builds of the library, bit for bit (four shapes: C2-like, key masks, no rotation, S = 256): run twice with --save
+(the second time with CM3P_HIP_LIB pointing at the other build), then --compare.  Used for the resident / whole-row forms of the dQ sweep.
+    python tools/band_resident_check.py --save /tmp/a.pt; CM3P_HIP_LIB=$PWD/_ab/other.so python tools/band_resident_check.py --save /tmp/b.pt
+    python tools/band_resident_check.py --compare /tmp/a.pt /tmp/b.pt"""
 import os
 import sys
 
