@@ -10,12 +10,12 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_bwd.hip", "attention_bwd_fused.hip", "attention_generic.hip", "head.hip", "conv.hip", "muon.hip"]
+SOURCES = ["norm.hip", "elementwise.hip", "gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_fwd.hip", "attention_bwd.hip", "attention_bwd_fused.hip", "attention_generic.hip", "head.hip", "conv.hip", "muon.hip"]
 LIB = os.path.join(CSRC, "libcm3p_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # hand-scheduled kernels: SLP-packing adjacent f32 multiplies into v_pk_mul_f32 costs register shuffles (v_mov / v_perm /
 # v_alignbit) around the bf16 packs and packed f32 VALU is slower beside MFMAs (MI355X_MICROARCH.md, cycle constants)
-EXTRA_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"], "attention_bwd_fused.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention_fwd.hip": ["-fno-slp-vectorize"], "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_bwd_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = True, check_isa: bool = True) -> 
 # The bounds-audit twin of the library (csrc/common.h, CM3P_DMA_AUDIT): the objects that stage operands by LDS-DMA are compiled a second
 # time with the recording hooks in; everything else is shared with the shipped library.  Debug artefact, loaded only by
 # tests/test_dma_audit_gpu.py (cm3p_build_ablation_flags() is non-zero for it, so _lib.load() refuses it as a product library).
-AUDIT_SOURCES = ["gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_bwd_fused.hip"]
+AUDIT_SOURCES = ["gemm.hip", "gemm256.hip", "gemm8p.hip", "attention.hip", "attention_fwd.hip", "attention_bwd_fused.hip"]
 AUDIT_LIB = os.path.join(CSRC, "libcm3p_hip_audit.so")
 
 

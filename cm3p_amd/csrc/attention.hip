@@ -731,8 +731,21 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const uint16_t* __restr
 
 }  // namespace
 
+// attention_fwd.hip: the global layers' forward as one software-pipelined stream per wave (r05; pre-scaled q only)
+int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, const int* cu_seqlens,
+                                int64_t total, hipStream_t s);
+// CM3P_ATTN_FWD_IMPL=wave3 keeps the global layers on attn_fwd_kernel (three compiler-scheduled waves per SIMD): the A/B partner and
+// the independent implementation the pipelined kernel is cross-checked against in the tests
+static bool fwd_pipelined() {
+    static const bool v = [] { const char* e = getenv("CM3P_ATTN_FWD_IMPL"); return !(e && e[0] == 'w'); }();
+    return v;
+}
+
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                            float scale, VarLen vl, int pre, hipStream_t s) {
+    // (TileDma::rows: 32-bit row * pitch source offsets, attn_common.h)
+    if (window < 0 && pre && fwd_pipelined() && (int64_t)S * 3 * nh * 128 < (int64_t(1) << 31))
+        return cm3p_launch_attn_fwd_global(qkv, out, lse, key_mask, B, S, nh, vl.cu, vl.total, s);
     // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
     // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
     const dim3 grid(((S + 127) / 128) * nh * B);  // 1-D: decode_block() maps it XCD-aware

@@ -301,7 +301,9 @@ int cm3p_ablation_flags_attention_bwd();
 int cm3p_ablation_flags_attention_bwd_fused();
 int cm3p_ablation_flags_gemm256();
 int cm3p_ablation_flags_gemm8p();
+int cm3p_ablation_flags_attention_fwd();
 #if CM3P_DMA_AUDIT
+int cm3p_audit_set_attention_fwd(void*);
 int cm3p_audit_set_gemm8p(void*);
 int cm3p_audit_set_gemm256(void*);
 int cm3p_audit_set_attention(void*);
@@ -312,7 +314,8 @@ extern "C" {
 
 int cm3p_build_ablation_flags(void) {
     return (cm3p_ablation_flags_attention() != 0) | (cm3p_ablation_flags_attention_bwd() != 0) << 1 | (cm3p_ablation_flags_attention_bwd_fused() != 0) << 2 |
-           (cm3p_ablation_flags_gemm256() != 0) << 3 | (cm3p_ablation_flags_gemm8p() != 0) << 4 | (CM3P_DMA_AUDIT != 0) << 5;
+           (cm3p_ablation_flags_gemm256() != 0) << 3 | (cm3p_ablation_flags_gemm8p() != 0) << 4 | (CM3P_DMA_AUDIT != 0) << 5 |
+           (cm3p_ablation_flags_attention_fwd() != 0) << 6;
 }
 
 int cm3p_debug_set_dma_audit(void* buf) {
@@ -321,6 +324,7 @@ int cm3p_debug_set_dma_audit(void* buf) {
     if (rc == CM3P_OK) rc = cm3p_audit_set_gemm256(buf);
     if (rc == CM3P_OK) rc = cm3p_audit_set_attention(buf);
     if (rc == CM3P_OK) rc = cm3p_audit_set_attention_bwd_fused(buf);
+    if (rc == CM3P_OK) rc = cm3p_audit_set_attention_fwd(buf);
     return rc;
 #else
     (void)buf;
