@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -38,6 +38,8 @@ SIGNATURES = {
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],
     "cm3p_gemm_wgrad_splits": [_L, _L, _L],
+    "cm3p_gemm8p_set_grid": [_I],
+    "cm3p_gemm8p_get_grid": [],
     "cm3p_build_ablation_flags": [],
     "cm3p_debug_set_dma_audit": [_P],
     "cm3p_cast_f32_bf16": [_P, _P, _L, _P],

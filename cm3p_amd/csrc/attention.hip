@@ -783,11 +783,12 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     if (stages & CM3P_ATTN_BWD_DQ) {
 #define CM3P_DQ_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, (const uint16_t*)out, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
         static Cm3pDevOnce once;  // (per device: common.h)
-        if (once.first()) {
-            const void* f[4] = {reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>),
-                                reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>)};
-            for (const void* k : f) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSlots * kDqStage);
-        }
+        const int rc_once = once.run([] {
+            return cm3p_set_max_lds({reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>),
+                                     reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>)},
+                                    kDqSlots * kDqStage);
+        });
+        if (rc_once != CM3P_OK) return rc_once;
         if (pre && key_mask) attn_bwd_dq_kernel<true, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
         else if (pre) attn_bwd_dq_kernel<true, false><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
         else if (key_mask) attn_bwd_dq_kernel<false, true><<<grid, 256, kDqSlots * kDqStage, s>>>(CM3P_DQ_ARGS);
@@ -798,10 +799,11 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     if (stages & CM3P_ATTN_BWD_DKV) {
 #define CM3P_DKV_ARGS (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, key_mask, S, nh, window, scale, cos_tab, sin_tab, pos_batch_stride, vl
         static Cm3pDevOnce once2;
-        if (once2.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSlots * kDkvStage);
-        }
+        const int rc_once = once2.run([] {
+            return cm3p_set_max_lds({reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>)},
+                                    kDkvSlots * kDkvStage);
+        });
+        if (rc_once != CM3P_OK) return rc_once;
         if (pre) attn_bwd_dkv_kernel<true><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
         else attn_bwd_dkv_kernel<false><<<grid, 256, kDkvSlots * kDkvStage, s>>>(CM3P_DKV_ARGS);
 #undef CM3P_DKV_ARGS

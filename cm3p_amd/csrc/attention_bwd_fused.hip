@@ -723,7 +723,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
 
 extern "C" {
 
-int cm3p_attn_bwd_fused_slab_group(int S) { return (S + 255) / 256 >= 24 ? 4 : 2; }
+// Key blocks per dQ slab.  The ONE place the group size is derived (r04 advisor: the Python side used to parse the override on its own
+// and more strictly than this file did; with CM3P_FUSED_SLAB_GROUP="4x" it issued the stage bits of G = 2 to a library running G = 4,
+// and two of every four key blocks were never added).  The override counts only when it is exactly "2" or "4"; it is read per call.
+int cm3p_attn_bwd_fused_slab_group(int S) {
+    const char* e = getenv("CM3P_FUSED_SLAB_GROUP");
+    if (e && (e[0] == '2' || e[0] == '4') && e[1] == '\0') return e[0] - '0';
+    return (S + 255) / 256 >= 24 ? 4 : 2;
+}
 
 int64_t cm3p_attn_bwd_fused_workspace_bytes(int B, int S, int nh) {
     if (B <= 0 || S <= 0 || nh <= 0) return 0;
@@ -752,9 +759,10 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
     // Key blocks per dQ slab: 2, or 4 from 24 key blocks (S > 5888) on.  Four halve the slabs the reduce pass reads (C4: 6.3 -> 3.1 ms
     // per step) and put three of four launches on the packed-bf16 atomic path (2-8 % slower than the storing one, and one rounding per
     // add): r04 one-call A/B C4 214.6 -> 213.2 ms, C2 (16 key blocks) 168.8 vs 168.8 - hence the length rule.  CM3P_FUSED_SLAB_GROUP=2 / 4
-    // overrides (read per call).  The workspace is sized for 2, the larger.
-    const char* env_g = getenv("CM3P_FUSED_SLAB_GROUP");
-    const int G = (env_g && (env_g[0] == '2' || env_g[0] == '4')) ? env_g[0] - '0' : cm3p_attn_bwd_fused_slab_group(S);
+    // overrides (cm3p_attn_bwd_fused_slab_group, which the caller asks too).  The workspace is sized for 2, the larger.
+    const int G = cm3p_attn_bwd_fused_slab_group(S);
+    // single-launch stage bits must name positions of THIS group size: a caller that derived another G would silently drop key blocks
+    CM3P_REQUIRE((stages & (7 * CM3P_ATTN_BWD_FUSED_MAIN_ADD1) & ~(((1 << (G - 1)) - 1) * CM3P_ATTN_BWD_FUSED_MAIN_ADD1)) == 0);
     if (stages & CM3P_ATTN_BWD_FUSED_PREP) {
         // the score accumulators start at -lse * log2(e) (pre: q carries scale * log2 e, the MFMA delivers log2 p) or at
         // -lse / scale (cm * (q.k - lse / scale) = log2 p)
@@ -767,12 +775,12 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
     const bool run_odd = stages & (CM3P_ATTN_BWD_FUSED_MAIN | CM3P_ATTN_BWD_FUSED_MAIN_ODD);
     if (run_even || run_odd || (stages & (7 * CM3P_ATTN_BWD_FUSED_MAIN_ADD1))) {
         static Cm3pDevOnce once;  // (per device: common.h)
-        if (once.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFLds);
-        }
+        const int rc_once = once.run([] {
+            return cm3p_set_max_lds({reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, false>), reinterpret_cast<const void*>(&attn_bwd_fused_kernel<true, true>),
+                                     reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, false>), reinterpret_cast<const void*>(&attn_bwd_fused_kernel<false, true>)},
+                                    kFLds);
+        });
+        if (rc_once != CM3P_OK) return rc_once;
         // G launches: the key blocks G k store their dQ partial to slab k, then the key blocks G k + 1, .. each add theirs to it (1-D
         // grids: decode_block() maps them XCD-aware)
         const int nkb = (S + 255) / 256;

@@ -458,10 +458,11 @@ int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const ui
     const VarLen vl{cu_seqlens, total};
     const dim3 grid(((S + 128 * U - 1) / (128 * U)) * nh * B);  // 1-D: decode_block() maps it XCD-aware
     static Cm3pDevOnce once;  // (per device: common.h)
-    if (once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGSlots * kGStageMask);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGSlots * kGStageNoMask);
-    }
+    const int rc_once = once.run([] {
+        return cm3p_set_max_lds({reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, true>), reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, false>)},
+                                kGSlots * kGStageMask);
+    });
+    if (rc_once != CM3P_OK) return rc_once;
     if (key_mask)
         attn_fwd_g_kernel<U, true><<<grid, 256, kGSlots * kGStageMask, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, vl);
     else

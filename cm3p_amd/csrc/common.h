@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <initializer_list>
+#include <mutex>
+
 #include "../../include/cm3p_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -147,15 +151,33 @@ static inline int cm3p_num_cu() {
     }
     return cu[d];
 }
-struct Cm3pDevOnce {  // `static Cm3pDevOnce once; if (once.first()) { ... }`: the body runs once per device
-    bool done[kCm3pMaxDevices] = {};
-    bool first() {
-        const int d = cm3p_current_device();
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+// `static Cm3pDevOnce once; rc = once.run([&] { ...; return CM3P_OK; });`: the body runs until it has SUCCEEDED once per device.  A device
+// is marked only after its body returned CM3P_OK (r04 advisor: the first form marked it before the body ran, so a failed
+// hipFuncSetAttribute was never retried and every later launch went out without the attribute), under a lock (two host threads on one
+// device cannot both skip while the attribute is still being applied); devices beyond the table run the body every time (the bodies are
+// idempotent attribute calls) instead of sharing slot 0.
+struct Cm3pDevOnce {
+    std::atomic<unsigned char> done[kCm3pMaxDevices] = {};
+    std::mutex mu;
+    template <class F>
+    int run(F&& body) {
+        int d = 0;
+        const bool tracked = hipGetDevice(&d) == hipSuccess && d >= 0 && d < kCm3pMaxDevices;
+        if (tracked && done[d].load(std::memory_order_acquire)) return CM3P_OK;
+        std::lock_guard<std::mutex> g(mu);
+        if (tracked && done[d].load(std::memory_order_relaxed)) return CM3P_OK;
+        const int rc = body();
+        if (rc == CM3P_OK && tracked) done[d].store(1, std::memory_order_release);
+        return rc;
     }
 };
+
+// dynamic LDS above the 64-KiB default for every kernel in the list
+static inline int cm3p_set_max_lds(std::initializer_list<const void*> kernels, int bytes) {
+    for (const void* k : kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return CM3P_ERR_LAUNCH;
+    return CM3P_OK;
+}
 
 static inline bool cm3p_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

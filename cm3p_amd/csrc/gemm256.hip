@@ -405,11 +405,13 @@ int launch256(const uint16_t* a, const uint16_t* b, void* C, const float* R, int
 #define CM3P_G256(E)                                                                                                     \
     {                                                                                                                    \
         static Cm3pDevOnce once;                                                                                         \
-        if (once.first()) {                                                                                              \
-            if (hipFuncSetAttribute((const void*)gemm256_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                             \
-                return CM3P_ERR_LAUNCH;                                                                                  \
-        }                                                                                                                \
+        const int rc_once = once.run([&] {                                                                               \
+            return hipFuncSetAttribute((const void*)gemm256_kernel<A_KC, B_KC, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds) == hipSuccess                                                           \
+                       ? CM3P_OK                                                                                         \
+                       : CM3P_ERR_LAUNCH;                                                                                \
+        });                                                                                                              \
+        if (rc_once != CM3P_OK) return rc_once;                                                                          \
         gemm256_kernel<A_KC, B_KC, E><<<grid, kThreads, lds, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope); \
     }
     switch (epi) {

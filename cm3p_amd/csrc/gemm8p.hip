@@ -614,19 +614,22 @@ int launch8p(const uint16_t* a, const uint16_t* b, void* C, const float* R, int6
     const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256);
     const int ntiles = tiles_m * tiles_n, total = ntiles * (batch > 0 ? batch : splits);
     const int num_cu = cm3p_num_cu();
-    int want = num_cu;
-    if (const char* e = getenv("CM3P_G8P_GRID")) {  // development switch: leave CUs to a kernel on another stream (tools/overlap_ab.py)
-        const int g = atoi(e);
-        if (g > 0) want = g;  // (more workgroups than CUs: the surplus is dispatched as CUs come free - tools/blocker_probe.py)
-    }
+    // cm3p_gemm8p_set_grid / CM3P_G8P_GRID: fewer workgroups leave CUs to a kernel on another stream (tools/overlap_ab.py), more than CUs
+    // are dispatched as CUs come free (tools/blocker_probe.py: what to run beside RCCL).  Any value is safe: a workgroup of this kernel
+    // never waits for another one (no instance has an inter-workgroup hand-off: split-K partials go to a separate reduce launch, REBAL only
+    // reorders a workgroup's own LDS reads), so surplus workgroups simply start when resident ones exit.
+    const int set = cm3p_gemm8p_get_grid();
+    const int want = set > 0 ? set : num_cu;
     const dim3 grid(total < want ? total : want);
 #define CM3P_G8P(E)                                                                                                               \
     {                                                                                                                             \
         static Cm3pDevOnce once;                                                                                                  \
-        if (once.first()) {                                                                                                       \
-            if (hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E, REBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) != hipSuccess) \
-                return CM3P_ERR_LAUNCH;                                                                                           \
-        }                                                                                                                         \
+        const int rc_once = once.run([&] {                                                                                        \
+            return hipFuncSetAttribute((const void*)gemm8p_kernel<A_KC, B_KC, E, REBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8p) == hipSuccess \
+                       ? CM3P_OK                                                                                                  \
+                       : CM3P_ERR_LAUNCH;                                                                                         \
+        });                                                                                                                       \
+        if (rc_once != CM3P_OK) return rc_once;                                                                                   \
         gemm8p_kernel<A_KC, B_KC, E, REBAL><<<grid, 512, kLds8p, s>>>(a, b, C, R, M, N, K, lda, ldb, ldc, tiles_n, ntiles, total, kchunk, c_split_stride, rope, bt, batch > 0 ? 1 : 0); \
     }
     switch (epi) {
@@ -690,6 +693,23 @@ int cm3p_gemm8p_dispatch(const void* A, const void* B, void* C, const float* R, 
 }
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
+static std::atomic<int> g_g8p_grid{-1};  // -1: not set yet, the environment is asked once
+extern "C" int cm3p_gemm8p_get_grid(void) {
+    int g = g_g8p_grid.load(std::memory_order_relaxed);
+    if (g < 0) {
+        const char* e = getenv("CM3P_G8P_GRID");
+        g = e ? atoi(e) : 0;
+        if (g < 0) g = 0;
+        g_g8p_grid.store(g, std::memory_order_relaxed);
+    }
+    return g;
+}
+extern "C" int cm3p_gemm8p_set_grid(int workgroups) {
+    if (workgroups < 0) return CM3P_ERR_INVALID;
+    g_g8p_grid.store(workgroups, std::memory_order_relaxed);
+    return CM3P_OK;
+}
+
 int cm3p_ablation_flags_gemm8p() { return (CM3P_G8P_ABL); }
 #if CM3P_DMA_AUDIT
 int cm3p_audit_set_gemm8p(void* buf) { return cm3p_audit_set_local(buf); }

@@ -282,13 +282,21 @@ def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, 
     return qkv
 
 
+def _attn_fwd_name(window: int, prescaled: bool, masked: bool, S: int, nh: int) -> str:
+    """The forward kernel a call lands on, as rocprofv3 names it (csrc/attention.hip: launch_attn_fwd): global layers with pre-scaled q run
+    the pipelined kernel of csrc/attention_fwd.hip unless CM3P_ATTN_FWD_IMPL=wave3 (or the sequence is too long for its 32-bit row offsets)."""
+    if window < 0 and prescaled and os.environ.get("CM3P_ATTN_FWD_IMPL", "")[:1] != "w" and S * 3 * nh * 128 < (1 << 31):
+        return "attn_fwd_g_kernel<4, " + ("true>" if masked else "false>")
+    return "attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>")
+
+
 def attn_fwd(qkv: Tensor, key_mask: Optional[Tensor], B: int, S: int, nh: int, window: int, scale: float, prescaled: bool = False):
     """prescaled: the q third already carries scale * log2(e) (qkv_linear_rope(..., q_scale=SOFTMAX_Q_SCALE))."""
     out = torch.empty((B * S, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     keys = S if window < 0 else min(S, 2 * window + 1)
     call("cm3p_attn_fwd", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(key_mask, torch.uint8), B, S, nh, window, scale, int(prescaled), stream(),
-         tag=_attn_tag("attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>"), window, prescaled), work=4.0 * B * nh * S * keys * 64)
+         tag=_attn_tag(_attn_fwd_name(window, prescaled, key_mask is not None, S, nh), window, prescaled), work=4.0 * B * nh * S * keys * 64)
     return out, lse
 
 
@@ -372,8 +380,7 @@ def _attn_bwd_fused(qkv, out, dout, lse, key_mask, cu, B, S, total, nh, scale, r
     rows = total if varlen else B * S
     fl = 2.0 * B * nh * S * S * 64  # one S x S x 64 product per (batch, head); SURVEY.md 8(d) credits four to the backward
     nkb = -(-S // 256)  # 256-key blocks; G of them share a dQ slab: the first of each group stores (one launch), the others add (G - 1 launches)
-    env_g = os.environ.get("CM3P_FUSED_SLAB_GROUP", "")
-    G = int(env_g) if env_g in ("2", "4") else query("cm3p_attn_bwd_fused_slab_group", S)
+    G = query("cm3p_attn_bwd_fused_slab_group", S)  # (the C side derives it, CM3P_FUSED_SLAB_GROUP included: one parse, one answer)
     n_store = -(-nkb // G)
     slabs = float(need) * 2.0 / G  # (the workspace is sized for groups of 2)
     # one C call per launch, so that every profiler tag is ONE kernel (one rocprof row): the storing launch, then the adding launches
@@ -419,7 +426,7 @@ def attn_fwd_varlen(qkv: Tensor, cu: Tensor, B: int, max_s: int, nh: int, window
     out = torch.empty((total, nh * 64), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((nh, total), dtype=torch.float32, device=qkv.device)
     call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(out), ptr(lse, torch.float32), ptr(cu, torch.int32), B, max_s, total, nh, window, scale, int(prescaled), stream(),
-         tag=_attn_tag("attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>"), window, prescaled, True))
+         tag=_attn_tag(_attn_fwd_name(window, prescaled, False, max_s, nh), window, prescaled, True))
     return out, lse
 
 

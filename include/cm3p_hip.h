@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 14
+#define CM3P_ABI_VERSION 15
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -117,6 +117,16 @@ int cm3p_audio_slots(const int64_t* ids, int64_t T, int64_t audio_token_id, int3
  * all tokens while its output is only a few hundred tiles. */
 int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream);
+
+/* Host-only, process-wide.  The big-shape GEMM (csrc/gemm8p.hip) is a persistent kernel: by default one 512-thread workgroup per CU walks the
+ * work items with a fixed stride.  workgroups > 0 launches that many instead (clamped to the number of work items): with MORE workgroups than
+ * CUs the surplus is dispatched wherever a CU comes free, which is what a data-parallel step wants while RCCL's channel workgroups hold
+ * CUs (the reference gets the same from DistributedDataParallel over NCCL, ref:train.py:360-375: its GEMMs are not persistent) - measured
+ * with 32 CUs held: +26..58 % per GEMM with one workgroup per CU, +7..10 % with 1024.  Safe for any value: no
+ * gemm8p instance waits on another workgroup (split-K partials are summed by a separate launch).  0 restores the default; until
+ * the first call the environment variable CM3P_G8P_GRID (read once) supplies the value.  Returns CM3P_ERR_INVALID for workgroups < 0. */
+int cm3p_gemm8p_set_grid(int workgroups);
+int cm3p_gemm8p_get_grid(void);
 
 /* Host-only.  The hand-scheduled kernels carry compile-time TIMING probes (macros CM3P_ABL, CM3P_FABL, CM3P_BABL, CM3P_G256_ABL,
  * CM3P_G8P_ABL: builds that skip barriers, loads or stores and whose results are wrong by construction; the _ablate.sh scripts under tools/ubench).

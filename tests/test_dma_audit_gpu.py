@@ -26,7 +26,10 @@ def test_the_shipped_library_has_no_audit_hooks():
 
 @pytest.mark.gpu
 def test_every_lds_dma_stream_stays_inside_its_operand():
-    assert os.path.exists(AUDIT_LIB), "build it with python -m cm3p_amd.build"
+    from cm3p_amd import build as B
+
+    B.build_audit(verbose=False)  # opt-in twin (python -m cm3p_amd.build --audit): compiled here when missing or stale
+    assert os.path.exists(AUDIT_LIB)
     env = dict(os.environ, CM3P_HIP_LIB=AUDIT_LIB, CM3P_ALLOW_ABLATED_LIB="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dma_audit.py")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
@@ -37,5 +40,5 @@ def test_every_lds_dma_stream_stays_inside_its_operand():
     # both big-shape GEMM kernels, both attention backward families and the packed-sequence forms were exercised
     names = " | ".join(r["case"] for r in cases)
     for needle in ("gemm 8p fwd", "gemm 256 fwd", "wgrad", "dgrad", "RoPE", "GeGLU", "batched", "sliding-window backward stage 1", "stage 2",
-                   "fused global backward (even", "fused global backward (odd", "packed"):
+                   "fused global backward (even", "fused global backward (odd", "packed", "global forward (pipelined) B=", "global forward (pipelined), packed"):
         assert needle in names, needle

@@ -115,6 +115,11 @@ def attention_cases():
         if masked:
             mask = torch.ones((B, S), dtype=torch.uint8, device=DEV)
             mask[:, S - S // 3:] = 0
+        # the pipelined global forward (attention_fwd.hip): K and V tiles, three tiles past the sequence's last one, and the mask bytes
+        fo, flse = torch.empty_like(o), torch.empty_like(lse)
+        audited(f"global forward (pipelined) B={B} S={S} mask={masked}",
+                lambda: call("cm3p_attn_fwd", ptr(qkv), ptr(fo), ptr(flse), ptr(mask, torch.uint8), B, S, nh, -1, scale, 1, stream()),
+                {2: qkv, 3: qkv, **({4: mask} if masked else {})})
         for stage, expect in ((1, {2: qkv, 3: qkv, **({4: mask} if masked else {})}), (2, {2: qkv, 3: do, 4: lse, 5: delta})):
             audited(f"sliding-window backward stage {stage} B={B} S={S} mask={masked}",
                     lambda: call("cm3p_attn_bwd", ptr(qkv), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dqkv), ptr(mask, torch.uint8), B, S, nh, 64, scale,
@@ -135,6 +140,9 @@ def attention_cases():
     qkv, o, do = bf(total, 3, nh, 64), bf(total, nh * 64), bf(total, nh * 64)
     lse = f32(nh, total)
     delta, dqkv = torch.zeros_like(lse), torch.empty_like(qkv)
+    fo, flse = torch.empty_like(o), torch.empty_like(lse)
+    audited(f"global forward (pipelined), packed {lens}",
+            lambda: call("cm3p_attn_fwd_varlen", ptr(qkv), ptr(fo), ptr(flse), ptr(cu, torch.int32), Bv, max_s, total, nh, -1, scale, 1, stream()), {2: qkv, 3: qkv})
     for stage, expect in ((1, {2: qkv, 3: qkv}), (2, {2: qkv, 3: do, 4: lse, 5: delta})):
         audited(f"sliding-window backward stage {stage}, packed {lens}",
                 lambda: call("cm3p_attn_bwd_varlen", ptr(qkv), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dqkv), ptr(cu, torch.int32), Bv, max_s, total, nh, 64,
