@@ -736,9 +736,9 @@ int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const ui
                                 int64_t total, hipStream_t s);
 // CM3P_ATTN_FWD_IMPL=wave3 keeps the global layers on attn_fwd_kernel (three compiler-scheduled waves per SIMD): the A/B partner and
 // the independent implementation the pipelined kernel is cross-checked against in the tests
-static bool fwd_pipelined() {
-    static const bool v = [] { const char* e = getenv("CM3P_ATTN_FWD_IMPL"); return !(e && e[0] == 'w'); }();
-    return v;
+static bool fwd_pipelined() {  // (read per call: the tests run both in one process)
+    const char* e = getenv("CM3P_ATTN_FWD_IMPL");
+    return !(e && e[0] == 'w');
 }
 
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,

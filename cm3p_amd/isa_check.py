@@ -138,7 +138,66 @@ def check_attention_bwd_fused(isa: str):
         _need(ring.count("v_exp_f32") == 384 and len(re.findall(r"v_exp_f32_e64 v\d+, v\d+ clamp", ring)) == 384, f"{sym}: exponentials / clamp")
 
 
-CHECKS = {"gemm8p.hip": check_gemm8p, "attention_bwd.hip": check_attention_bwd, "attention_bwd_fused.hip": check_attention_bwd_fused}
+# ------------------------------------------------------------------------------------------------ attention_fwd.hip
+def hot_path(lines: list[str], lo: int, hi: int):
+    """(index, line) of lines lo..hi as a wave executes them when every forward conditional branch that jumps over a block is TAKEN:
+    the blocks such branches skip are the cold blocks of a hand-placed stream (masked tile, reference move)."""
+    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+    i = lo
+    while i <= hi:
+        l = lines[i]
+        yield i, l
+        m = re.search(r"s_cbranch_\S+\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and i < labels[m.group(1)] <= hi:
+            i = labels[m.group(1)]
+            continue
+        if m and labels.get(m.group(1)) == lo:  # (a rotated loop: the last cold block sits between this branch and the latch)
+            return
+        i += 1
+
+
+def check_attention_fwd(isa: str):
+    """The pipelined global forward (attention_fwd.hip).  Its loop body is four tiles (= the ring); per tile and wave exactly four
+    LDS-DMA pieces (+ one 64-byte mask piece in the MASK instance) behind ONE counted wait, vmcnt(4) (5), directly in front of the one
+    barrier; nothing else touches vector memory and nothing is spilled - a compiler-issued scratch reload or global load would be
+    counted by vmcnt and retire in order, i.e. drain the ring.  The score product must be the VGPR-result form with both operands in
+    AGPRs, the output product the AGPR-accumulating form.  On the HOT path (cold blocks skipped) per 16 MFMAs: 32 exponentials, at
+    most 110 vector instructions in all, no v_mov, and accumulator copies only as the loop header's one block (r04 verdict item 1e)."""
+    no_scratch(isa, "attention_fwd.hip")
+    for mask in (False, True):
+        bodies = kernel_bodies(isa, "attn_fwd_g_kernelILi4ELb%dE" % int(mask))
+        _need(len(bodies) == 1, f"attn_fwd_g_kernel<4, {mask}>: {len(bodies)} instances")
+        sym, body = next(iter(bodies.items()))
+        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_32x32x16_bf16") == 256]
+        _need(ring, f"{sym}: four-tile loop (256 MFMAs) not found")
+        ring = ring[-1]
+        nd = "5" if mask else "4"
+        _need(ring.count("global_load_lds_dwordx4") == 16 and ring.count("global_load_lds_ubyte") == (4 if mask else 0), f"{sym}: LDS-DMA count per loop trip changed")
+        _need(len(re.findall(r"\bglobal_(load|store|atomic)_", ring)) == 16 + (4 if mask else 0) and not re.search(r"\bbuffer_|\bflat_|scratch_", ring),
+              f"{sym}: stray vector-memory instruction in the loop")
+        _need(ring.count("s_barrier") == 4, f"{sym}: {ring.count('s_barrier')} barriers per loop trip, expected 4")
+        _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == [nd] * 4, f"{sym}: the loop's vector-memory waits are not four vmcnt({nd})")
+        for m in re.finditer(r"s_waitcnt vmcnt\(\d+\)", ring):
+            _need(re.match(r"\s*s_barrier", ring[m.end():]), f"{sym}: a counted wait is not directly in front of its barrier")
+        _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], a\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\]", ring)) == 128, f"{sym}: score MFMA form (VGPR result, AGPR operands)")
+        _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1", ring)) == 128, f"{sym}: output MFMA form (AGPR accumulator tied to itself)")
+        # the hot path of the loop trip
+        lines = body.split("\n")
+        first = body[:body.index(ring)].count("\n")
+        hot = [l.split()[0] for _, l in hot_path(lines, first, first + ring.count("\n")) if l.startswith("\t") and l.split()]
+        n_mfma = sum(o.startswith("v_mfma") for o in hot)
+        _need(n_mfma == 256, f"{sym}: {n_mfma} MFMAs on the hot path of a loop trip")
+        _need(sum(o.startswith("v_exp_f32") for o in hot) == 512, f"{sym}: exponentials on the hot path")
+        vec = sum(o.startswith("v_") and not o.startswith("v_mfma") for o in hot)
+        _need(vec <= 110 * 16, f"{sym}: {vec / 16:.1f} vector instructions per 16 MFMAs on the hot path (bound: 110)")
+        acc = sum("accvgpr" in o for o in hot)
+        _need(acc <= 32, f"{sym}: {acc} accumulator copies on the hot path of a loop trip (the loop header's block is 32)")
+        _need(sum(o.startswith("v_mov_b32") for o in hot) <= 8, f"{sym}: v_mov on the hot path")
+        _need(body.count("s_waitcnt vmcnt(0)") >= 2, f"{sym}: the prologue wait / the final drain of the ring is missing")
+
+
+CHECKS = {"gemm8p.hip": check_gemm8p, "attention_fwd.hip": check_attention_fwd, "attention_bwd.hip": check_attention_bwd,
+          "attention_bwd_fused.hip": check_attention_bwd_fused}
 
 
 def check_file(src: str, flags: list[str]) -> None:

@@ -25,6 +25,12 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
+def _lib_query(name, *args):
+    from cm3p_amd import _lib
+
+    return _lib.query(name, *args)
+
+
 def _err(a, b):
     return (a.float().cpu() - b.float().cpu()).abs().max().item()
 
@@ -719,8 +725,55 @@ def test_audio_conv_frontend_matches_conv1d(K):
 
 
 # ------------------------------------------------------------------------------------------------- unpadded attention
-@pytest.mark.parametrize("window", [-1, 64])
-def test_attention_varlen_equals_padded_on_valid_rows(K, window):
+@pytest.mark.parametrize("S,lens,nh", [(1100, [1100, 1023, 65, 1], 2), (512, None, 3), (4096 + 77, [4096 + 77, 2049], 1), (200, [200, 1, 199], 2)])
+def test_pipelined_global_forward_agrees_with_the_three_wave_kernel(K, monkeypatch, S, lens, nh):
+    """Global layers with pre-scaled q have two forward implementations behind one call: the software-pipelined one-wave-per-SIMD kernel
+    (attention_fwd.hip, the default) and attn_fwd_kernel (attention.hip, CM3P_ATTN_FWD_IMPL=wave3).  Same mathematics, different order
+    of the row sums and a different moment at which the lazily moved reference point moves: outputs agree to bf16 rounding, lse to
+    fp32 rounding, rows without a visible key are exact zeros / +inf in both, and the pipelined kernel is bit-reproducible."""
+    g = torch.Generator().manual_seed(S + nh)
+    B = 2 if lens is None else len(lens)
+    qkv = _bf(torch.randn(B, S, 3, nh, 64, generator=g)).to(DEV)
+    qkv[:, :, 0] = (qkv[:, :, 0].float() * K.SOFTMAX_Q_SCALE).to(torch.bfloat16)
+    qkv[:, S // 2:, 1] *= 4.0  # late, much larger scores: the reference point moves long after the first tile
+    km = None
+    if lens is not None:
+        km = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).to(torch.uint8).to(DEV)
+        km[0, 3] = 0  # a hole inside the valid range
+    monkeypatch.setenv("CM3P_ATTN_FWD_IMPL", "wave3")
+    o3, l3 = K.attn_fwd(qkv, km, B, S, nh, -1, 0.125, prescaled=True)
+    monkeypatch.delenv("CM3P_ATTN_FWD_IMPL")
+    o1, l1 = K.attn_fwd(qkv, km, B, S, nh, -1, 0.125, prescaled=True)
+    o2, l2 = K.attn_fwd(qkv, km, B, S, nh, -1, 0.125, prescaled=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    fin = torch.isfinite(l3)
+    assert torch.equal(fin, torch.isfinite(l1))
+    assert (l1[fin] - l3[fin]).abs().max().item() <= 2e-5
+    if (~fin).any():
+        assert bool((l1[~fin] == float("inf")).all())
+    # one bf16 rounding apart at most (plus the fp32 reassociation of a 64-term dot product)
+    d = (o1.float() - o3.float()).abs()
+    assert (d <= 0.0079 * o3.float().abs() + 2e-3).all(), d.max().item()
+
+
+@pytest.mark.parametrize("nkb,lens", [(1, None), (2, [512 - 17, 300]), (3, None), (5, [1280 - 100, 1025, 7])])
+def test_fused_backward_with_four_key_blocks_per_slab_at_short_sequences(K, monkeypatch, nkb, lens):
+    """CM3P_FUSED_SLAB_GROUP=4 (the rule only picks it from 24 key blocks = S > 5888 on, which no kernel test reaches): partial groups,
+    a single key block, padded rows - against the fp32 reference and against the group size 2 the same call picks by itself."""
+    S = 256 * nkb - (17 if lens is None else 0)
+    if lens is not None:
+        S = lens[0]
+    monkeypatch.setenv("CM3P_ATTN_BWD_FUSED", "1")
+    monkeypatch.setenv("CM3P_FUSED_SLAB_GROUP", "4")
+    assert _lib_query("cm3p_attn_bwd_fused_slab_group", S) == 4
+    _attn_case(K, 2 if lens is None else len(lens), S, 2, -1, lens, 77 + nkb, prescaled=True)
+    monkeypatch.setenv("CM3P_FUSED_SLAB_GROUP", "4x")  # not exactly "2" / "4": ignored by the one place that parses it
+    assert _lib_query("cm3p_attn_bwd_fused_slab_group", S) == 2
+
+
+@pytest.mark.parametrize("window,prescaled", [(-1, False), (-1, True), (64, False)])
+def test_attention_varlen_equals_padded_on_valid_rows(K, window, prescaled):
     """cm3p_attn_*_varlen on packed sequences == cm3p_attn_* on the right-padded batch, bit for bit, on every valid row
     (masked keys contribute exact zeros, so packing must not change a single bit), forward and backward with the RoPE epilogue."""
     torch.manual_seed(0)
@@ -734,8 +787,9 @@ def test_attention_varlen_equals_padded_on_valid_rows(K, window):
     do = do * mask.reshape(B * S, 1).to(do.dtype)  # padded queries carry no gradient (in the model they never reach the loss)
     inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=DEV, dtype=torch.float32) / 64))
     cos, sin = K.rope_table(torch.arange(S, device=DEV), inv_freq)
-    out, lse = K.attn_fwd(qkv, mask, B, S, nh, window, 0.125)
-    dqkv = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, window, 0.125, (cos, sin), False)
+    # (prescaled: the global forward runs the pipelined kernel of attention_fwd.hip, whose masked tiles must also contribute exact zeros)
+    out, lse = K.attn_fwd(qkv, mask, B, S, nh, window, 0.125, prescaled)
+    dqkv = K.attn_bwd(qkv, out, do, lse, mask, B, S, nh, window, 0.125, (cos, sin), False, prescaled)
 
     idx = torch.nonzero(mask.flatten()).flatten()
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
@@ -743,8 +797,8 @@ def test_attention_varlen_equals_padded_on_valid_rows(K, window):
     do_p = do[idx].contiguous()
     pos = (idx % S).contiguous()
     cos_p, sin_p = K.rope_table(pos, inv_freq)
-    out_p, lse_p = K.attn_fwd_varlen(qkv_p, cu, B, max(lens), nh, window, 0.125)
-    dqkv_p = K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, window, 0.125, (cos_p, sin_p))
+    out_p, lse_p = K.attn_fwd_varlen(qkv_p, cu, B, max(lens), nh, window, 0.125, prescaled)
+    dqkv_p = K.attn_bwd_varlen(qkv_p, out_p, do_p, lse_p, cu, B, max(lens), nh, window, 0.125, (cos_p, sin_p), prescaled)
     torch.cuda.synchronize()
     assert torch.equal(out_p, out[idx])
     lse_rows = lse.permute(1, 0, 2).reshape(nh, B * S)[:, idx]  # [B, nh, S] -> [nh, total]

@@ -183,6 +183,74 @@ def test_c4_loss_at_the_real_batch_of_16(weights):
     _check_real_batch(weights, 16, 8192, 2025, "C4 B=16 forward")
 
 
+def _check_backward_at_real_batch(weights, B, S, seed, rows, tag):
+    """The beatmap tower's BACKWARD at the benched batch (r04 verdict: the 131 072-row grids, the 1.65 / 3.3 GB dQ-slab workspace with
+    64-bit offsets and the four-key-block slab groups had only ever been compared with themselves).  The upstream gradient is non-zero on
+    `rows` only - loss = sum_i <pooled[rows[i]], r_i> - so every backward launch has the full-batch grid and workspace while the expected
+    weight gradients are the sum of len(rows) single-sample oracle backward passes (samples do not interact inside a tower without
+    padding, ref:cm3p/modeling_cm3p.py:942-972); embedding rows that only the OTHER samples' tokens touch must receive exact zeros."""
+    from oracle import cm3p_oracle as O
+
+    batch = O.synthetic_batch(CFG, B=B, S=S, L=256, seed=seed)
+    ids, mask = batch["input_ids"], batch["attention_mask"]
+    for b in rows:  # token ids 5 .. 8 are left to the samples WITHOUT an upstream gradient: their embedding rows must stay exactly zero
+        ids[b][(ids[b] >= 5) & (ids[b] <= 8)] = 9
+    g = torch.Generator().manual_seed(seed + 1)
+    r = torch.randn(len(rows), 768, generator=g)
+    keys = [k for k in GRAD_KEYS if k.startswith("beatmap_model.")]
+    leaves = {k: weights[k].clone().requires_grad_(True) for k in keys}
+    sd2 = dict(weights)
+    sd2.update(leaves)
+    cfg = O.resolve_config(CFG)
+    t0 = time.time()
+    want_pooled = []
+    for i, b in enumerate(rows):
+        _, p, _ = O.beatmap_tower(sd2, cfg["beatmap_config"], ids[b:b + 1], mask[b:b + 1])
+        (p * r[i:i + 1]).sum().backward()
+        want_pooled.append(p.detach())
+    secs = time.time() - t0
+
+    model = _hip_model(weights)
+    model.zero_grad(set_to_none=True)
+    out = model.beatmap_model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV))
+    pooled = out.pooler_output
+    assert pooled.shape == (B, 768)
+    (pooled[torch.tensor(rows, device=DEV)] * r.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    _record(tag, "oracle_seconds", secs)
+    _record(tag, "pooled", _rel(pooled[torch.tensor(rows, device=DEV)], torch.cat(want_pooled)))
+    params = dict(model.named_parameters())
+    checked = 0
+    for k in keys:
+        gw, gg = leaves[k].grad, params[k].grad
+        assert gg is not None and torch.isfinite(gg).all(), f"{tag}: {k}"
+        e = _rel(gg, gw)
+        _record(tag, "grad." + k, e)
+        assert e <= TOL["grad"], f"{tag}: grad {k} rel-L2 {e:.3e}"
+        checked += 1
+    assert checked >= 5
+    # token-embedding rows touched by none of the selected samples: exact zeros (the other B - len(rows) samples contribute nothing)
+    table_grad = params["beatmap_model.encoder.embeddings.tok_embeddings.weight"].grad
+    touched = torch.zeros(table_grad.shape[0], dtype=torch.bool)
+    touched[ids[rows].reshape(-1)] = True
+    others = torch.zeros_like(touched)
+    others[ids.reshape(-1)] = True
+    only_others = (others & ~touched).to(DEV)
+    assert int(only_others.sum()) >= 4
+    assert table_grad[only_others].abs().max().item() == 0.0
+    _record(tag, "rows_only_other_samples_touch", float(only_others.sum()))
+
+
+def test_c2_backward_at_the_real_batch_of_32(weights):
+    """BASELINE configs[1] AS BENCHED, backward: B = 32 x S = 4096, upstream gradient on 4 of the 32 samples."""
+    _check_backward_at_real_batch(weights, 32, 4096, 3031, [0, 9, 22, 31], "C2 B=32 backward")
+
+
+def test_c4_backward_at_the_real_batch_of_16(weights):
+    """BASELINE configs[3] AS BENCHED, backward: B = 16 x S = 8192 (four key blocks per dQ slab), upstream gradient on 3 of the 16."""
+    _check_backward_at_real_batch(weights, 16, 8192, 3032, [1, 8, 15], "C4 B=16 backward")
+
+
 def test_c2_shape_full_depth_forward_backward(weights):
     """BASELINE configs[1] shape: S = 4096 / L = 256, all 22 + 6 layers, B = 2, one optimizer-free step."""
     from oracle import cm3p_oracle as O

@@ -10,20 +10,12 @@ import re
 import sys
 
 
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from cm3p_amd.isa_check import hot_path  # noqa: E402  (the same walker tests/test_kernel_isa.py pins the kernel with)
+
+
 def hot_lines(body, lo, hi):
-    """walks lines lo..hi, following `s_cbranch_* L` when L is a forward label inside the range (= the cold block is skipped)"""
-    labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
-    i = lo
-    out = []
-    while i <= hi:
-        l = body[i]
-        m = re.search(r"s_cbranch_\S+\s+(\.LBB\d+_\d+)", l)
-        out.append((i, l))
-        if m and m.group(1) in labels and i < labels[m.group(1)] <= hi:
-            i = labels[m.group(1)]
-            continue
-        i += 1
-    return out
+    return list(hot_path(body, lo, hi))
 
 
 def main():
