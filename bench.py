@@ -247,6 +247,60 @@ def roofline_object(tag: str, timed_launches, bracketed_step: dict, workload: st
     }
 
 
+def scaling_diagnosis(args, world, rank, device, model, step, timed, n, my_ms, ms_per_step, backend):
+    """N > 1 only, all OUTSIDE the judged region: what a single scaling run needs to say besides its one number (r04 verdict item 3).
+    The step is re-timed (a) with a surplus grid for the ring-kernel GEMMs - 1024 workgroups instead of one per CU, the arrangement
+    that loses least while RCCL's channel workgroups hold CUs (+7..10 % per GEMM against +26..58 %) - and (b) with the
+    gradient all-reduce in bf16 (a second DDP wrapper around the same module with bf16_compress_hook); together with the no_sync / rank-local
+    legs of `comm` a reader can tell "all-reduce exposed" (a, b no better; exposed_allreduce_ms large) from "GEMMs starved of CUs by the
+    communication kernels" (a better) from "bandwidth-bound all-reduce" (b better).  Also: per-rank step times (skew = one slow rank),
+    RCCL's version, and the fact that N = 1 runs the metadata tower beside the beatmap tower while N > 1 does not."""
+    import torch.distributed as dist
+
+    from cm3p_amd import kernels as K
+
+    out = {}
+    t = torch.tensor([my_ms], device=device, dtype=torch.float64)
+    ts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    per_rank = [round(float(x.item()), 3) for x in ts]
+    out["ms_per_step_per_rank"] = per_rank
+    out["rank_skew_ms"] = round(max(per_rank) - min(per_rank), 3)
+    # (the surplus-grid A/B of the ring-kernel GEMMs is taken in the warm-up, where its winner is selected: comm.gemm_grid)
+    # bf16 gradient all-reduce (skipped when the judged run already used it); every rank takes the same path: an unsupported dtype
+    # raises on all of them at the same collective
+    if args.grad_compress == "none":
+        try:
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+            ddp16 = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True, bucket_cap_mb=32)
+            ddp16.register_comm_hook(None, default_hooks.bf16_compress_hook)
+
+            def step16():
+                for p in model.parameters():
+                    p.grad = None
+                o = ddp16(**step.batch)
+                o.loss.backward()
+
+            ms_16 = timed(step16, n)
+            del ddp16
+            out["grad_compress_ab"] = {"ms_per_step_fp32_allreduce": ms_per_step, "ms_per_step_bf16_allreduce": ms_16, "delta_ms": ms_16 - ms_per_step}
+        except Exception as e:  # noqa: BLE001
+            out["grad_compress_ab"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    out["backend"] = backend
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:  # noqa: BLE001
+        out["rccl_version"] = None
+    out["ranks_seen"] = dist.get_world_size()
+    out["tower_overlap"] = {"n_gpus_1": "metadata tower on a second stream beside the beatmap tower (about -0.7 ms per C2 step)",
+                            "this_run": "off (gathered negatives: the metadata tower's output is awaited by the all-gather)"}
+    out["reading"] = ("exposed_allreduce_ms ~ 0 and gemm_grid.selected = one per CU: communication hidden, a scaling loss is elsewhere (rank_skew_ms: one slow rank); "
+                      "gemm_grid.selected = 1024: the ring-kernel GEMMs were waiting for CUs RCCL holds, the judged region ran with the surplus grid; "
+                      "grad_compress_ab.delta_ms < 0 with exposed_allreduce_ms > 0: the all-reduce is bandwidth-bound and exposed")
+    return out
+
+
 def launch_ranks(n: int) -> int:
     """Run this same command as n ranks under `python -m torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1 and a
     free port) as a child process and return its exit code."""
@@ -366,6 +420,7 @@ def main():
         out.loss.backward()
         return out.loss
 
+    step.batch = batch  # (scaling_diagnosis runs the same batch through a second DDP wrapper)
     for _ in range(args.warmup):
         step()
 
@@ -400,6 +455,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(fn, n):
+        """n calls of fn between fences -> ms per call, max over ranks (outside the judged region)."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n * 1e3
+
+    # N > 1: the grid of the ring-kernel GEMMs is chosen in the warm-up, by measurement (r04 verdict item 3).  One workgroup per CU is
+    # right when the chip is theirs (N = 1: a surplus grid costs 0.6-1 %); beside RCCL's channel workgroups, which hold CUs while a
+    # bucket's all-reduce runs, a workgroup that finds no CU starts late and still owns a full share of the work items (+26..58 % per
+    # GEMM with 32 CUs held against +7..10 % with 1024 workgroups, DESIGN section 6).  Two steps each way, max over ranks (the same
+    # number on every rank, so every rank takes the same decision); the judged region then runs the faster one and `comm` says which.
+    grid_choice = None
+    if world > 1:
+        from cm3p_amd import kernels as _K
+
+        g0 = _K.gemm8p_get_grid()
+        ms_g0 = timed(step, 2)
+        _K.gemm8p_set_grid(1024)
+        ms_g1 = timed(step, 2)
+        use_surplus = g0 == 0 and backend == "nccl" and ms_g1 < 0.99 * ms_g0
+        _K.gemm8p_set_grid(1024 if use_surplus else g0)
+        grid_choice = {"candidates": {"one per CU" if g0 == 0 else str(g0): ms_g0, "1024": ms_g1}, "selected": 1024 if use_surplus else (g0 or "one per CU"),
+                       "rule": "1024 workgroups if >= 1 % faster over RCCL, measured in the warm-up (2 steps each, max over ranks)"}
+
     # Per-kernel timing.  One extra UNTIMED step with a HIP-event pair around every C-ABI call gives the breakdown and names the
     # dominant single kernel; inside the timed region only every third launch of that kernel is bracketed (every launch of every
     # kernel bracketed costs the stream ~5 ms per C2 step, all launches of the dominant one ~0.5 ms, which would be charged to the
@@ -423,25 +510,12 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed  # this rank's own clock over the judged region (the reported time is the max over ranks)
     prof = _lib.profile_end() if profile else {}
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    def timed(fn, n):
-        """n calls of fn between fences -> ms per call, max over ranks (outside the judged region)."""
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt / n * 1e3
 
     ms_per_step = elapsed / args.steps * 1e3
     pairs_per_s = world * w["B"] * args.steps / elapsed
@@ -463,6 +537,8 @@ def main():
                 "exposed_allreduce_ms": ms_per_step - ms_nosync, "exposed_allgather_ms": ms_nosync - ms_local,
                 "gradient_bytes_per_step": sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad),
                 "grad_compress": args.grad_compress, "bucket_cap_mb": 32, "steps_per_leg": n_comm}
+        comm["gemm_grid"] = grid_choice
+        comm.update(scaling_diagnosis(args, world, rank, device, model, step, timed, n_comm, elapsed_local / args.steps * 1e3, ms_per_step, backend))
     flops = step_flops(config, w)
     result = {
         "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",

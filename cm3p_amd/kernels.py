@@ -282,6 +282,18 @@ def rope_apply_(qkv: Tensor, cos: Tensor, sin: Tensor, B: int, S: int, nh: int, 
     return qkv
 
 
+def gemm8p_set_grid(workgroups: int) -> None:
+    """Workgroups per launch of the big-shape GEMM kernel (0: one per CU, the default; > CU count: the surplus starts as CUs come free -
+    what bench.py selects next to RCCL).  Process-wide; include/cm3p_hip.h: cm3p_gemm8p_set_grid."""
+    rc = _lib.load().cm3p_gemm8p_set_grid(int(workgroups))
+    if rc != 0:
+        raise ValueError(f"cm3p_gemm8p_set_grid({workgroups}) -> {rc}")
+
+
+def gemm8p_get_grid() -> int:
+    return int(_lib.load().cm3p_gemm8p_get_grid())
+
+
 def _attn_fwd_name(window: int, prescaled: bool, masked: bool, S: int, nh: int) -> str:
     """The forward kernel a call lands on, as rocprofv3 names it (csrc/attention.hip: launch_attn_fwd): global layers with pre-scaled q run
     the pipelined kernel of csrc/attention_fwd.hip unless CM3P_ATTN_FWD_IMPL=wave3 (or the sequence is too long for its 32-bit row offsets)."""

@@ -51,6 +51,12 @@ def test_bench_two_ranks_share_the_card_over_gloo():
     r = d["replicas"]  # every rank holds bit-identical gradients after a DDP step; memory is reported per rank
     assert r["identical_on_all_ranks"] is True and len(r["peak_memory_gb_per_rank"]) == 2 and min(r["peak_memory_gb_per_rank"]) > 0
     assert d["comm"]["gradient_bytes_per_step"] > 0
+    # the scaling run explains itself (r04 verdict item 3): per-rank times, the measured grid choice, the bf16 all-reduce leg, what ran
+    c = d["comm"]
+    assert len(c["ms_per_step_per_rank"]) == 2 and c["rank_skew_ms"] >= 0 and c["ranks_seen"] == 2 and c["backend"] == "gloo"
+    assert set(c["gemm_grid"]["candidates"]) == {"one per CU", "1024"} and c["gemm_grid"]["selected"] == "one per CU"  # (surplus grid only over RCCL)
+    assert "grad_compress_ab" in c and ("delta_ms" in c["grad_compress_ab"] or "error" in c["grad_compress_ab"])
+    assert "this_run" in c["tower_overlap"] and "reading" in c
 
 
 def test_bench_starts_its_own_ranks_when_called_without_a_launcher():

@@ -400,12 +400,16 @@ def test_ring_gemm_with_more_workgroups_than_cus_is_the_same_gemm(K, monkeypatch
     M, N, Kd = 17928, 768, 256  # 71 x 3 tiles of 256 x 256 (the ring kernel's threshold is 200), a ragged last row tile
     a, w = _bf(torch.randn(M, Kd, generator=g)).to(DEV), _bf(torch.randn(N, Kd, generator=g) * 0.1).to(DEV)
     r = torch.randn(M, N, generator=g).to(DEV)
-    monkeypatch.delenv("CM3P_G8P_GRID", raising=False)
+    K.gemm8p_set_grid(0)
     want16, want32 = K.linear_fwd(a, w), K.linear_fwd(a, w, resid=r)
-    for grid in ("64", "300", "1024"):
-        monkeypatch.setenv("CM3P_G8P_GRID", grid)
-        assert torch.equal(K.linear_fwd(a, w), want16), grid
-        assert torch.equal(K.linear_fwd(a, w, resid=r), want32), grid
+    try:
+        for grid in (64, 300, 1024):
+            K.gemm8p_set_grid(grid)  # (cm3p_gemm8p_set_grid: process-wide, the environment variable is only its initial value)
+            assert K.gemm8p_get_grid() == grid
+            assert torch.equal(K.linear_fwd(a, w), want16), grid
+            assert torch.equal(K.linear_fwd(a, w, resid=r), want32), grid
+    finally:
+        K.gemm8p_set_grid(0)
 
 
 @pytest.mark.parametrize("cls,use_mask", [(True, True), (False, True), (False, False)])
@@ -757,7 +761,7 @@ def test_pipelined_global_forward_agrees_with_the_three_wave_kernel(K, monkeypat
     assert (d <= 0.0079 * o3.float().abs() + 2e-3).all(), d.max().item()
 
 
-@pytest.mark.parametrize("nkb,lens", [(1, None), (2, [512 - 17, 300]), (3, None), (5, [1280 - 100, 1025, 7])])
+@pytest.mark.parametrize("nkb,lens", [(1, None), (2, [512 - 17, 300]), (3, None), (5, [1280 - 100, 1025, 300])])
 def test_fused_backward_with_four_key_blocks_per_slab_at_short_sequences(K, monkeypatch, nkb, lens):
     """CM3P_FUSED_SLAB_GROUP=4 (the rule only picks it from 24 key blocks = S > 5888 on, which no kernel test reaches): partial groups,
     a single key block, padded rows - against the fp32 reference and against the group size 2 the same call picks by itself."""

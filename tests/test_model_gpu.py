@@ -29,17 +29,28 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
-# Fixture tolerances: <= 3 x the error MEASURED on MI355X per quantity, maximum over the cases and over the padded / unpadded executions
-# (profiles/r05_fixture_errors.json is the run they were cut from; every run writes gpurun_out/fixture_errors.json).  r01-r04 used
-# 3e-2 / 2e-2 / 6e-2 across the board, 10-30 x what these kernels measure: a 5 x regression would have passed.
+# Fixture tolerances.  FIX_TOL is the class bound of r01-r04 (the O(1)-scale golden weights make attention logits deliberately sharp: the
+# worst case of a class sits at a third to a half of it).  Since r05 every single (case, quantity) is ALSO held to 3 x the error measured for
+# it on MI355X (tests/golden/fixture_errors_r05.json, written by this very test; the kernels are bit-reproducible, so a run repeats its
+# errors exactly): the typical case measures 3-10 x below its class bound, and a 5 x regression there used to pass.
 FIX_TOL = dict(loss=3e-2, logits=3e-2, embeds=2e-2, pooled=2e-2, hidden=2e-2, mlm_logits=3e-2, audio=2e-2, grad=6e-2)
 FIX_MEASURED: dict = {}
+try:
+    import json as _json
+
+    FIX_BASE = _json.load(open(os.path.join(GOLD, "fixture_errors_r05.json")))["measured"]
+except OSError:
+    FIX_BASE = {}
 
 
 def _fix(tag: str, key: str, value: float, bound: str):
-    """records the error and asserts it against FIX_TOL[bound]"""
+    """records the error and asserts it against min(class bound, 3 x the committed measurement of this case and quantity)"""
     FIX_MEASURED.setdefault(tag, {})[key] = float(value)
-    assert value <= FIX_TOL[bound], f"{tag}: {key} = {value:.3e} > {FIX_TOL[bound]:.1e}"
+    tol = FIX_TOL[bound]
+    base = FIX_BASE.get(tag, {}).get(key)
+    if base is not None:
+        tol = min(tol, max(3.0 * base, 1e-5))
+    assert value <= tol, f"{tag}: {key} = {value:.3e} > {tol:.2e}"
 
 
 @pytest.fixture(scope="module", autouse=True)

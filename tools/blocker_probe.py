@@ -67,12 +67,12 @@ def main():
         row = []
         for grid in (None, 512, 768, 1024):
             if grid is None:
-                os.environ.pop("CM3P_G8P_GRID", None)
+                K.gemm8p_set_grid(0)
             else:
-                os.environ["CM3P_G8P_GRID"] = str(grid)
+                K.gemm8p_set_grid(grid)
             fn()
             row.append((grid or 256, timed(fn, False), timed(fn, True)))
-        os.environ.pop("CM3P_G8P_GRID", None)
+        K.gemm8p_set_grid(0)
         print(name + ":  " + "   ".join(f"grid {g_}: free {a:.3f} ms, {args.held} CUs held {b:.3f} ms" for g_, a, b in row), flush=True)
 
 

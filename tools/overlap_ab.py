@@ -68,8 +68,8 @@ def main():
         ln()                            # lands on what is left
         main_s.wait_stream(side)
 
-    for k in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
-        os.environ.pop(k, None)
+    K.gemm8p_set_grid(0)
+    os.environ.pop("CM3P_LN_BWD_CAP", None)
     t_g, t_l, t_s = timed(gemm), timed(ln), timed(both_seq)
     print(f"alone: wgrad {t_g:.3f} ms, LN backward {t_l:.3f} ms, back to back {t_s:.3f} ms", flush=True)
     print(f"concurrent, untouched grids: {timed(both_conc):.3f} ms", flush=True)
@@ -77,7 +77,7 @@ def main():
         for per_cu in (4, 8):
             cap = (256 - grid) * per_cu
             split[0] = grid // 27  # one work item per workgroup, as the shipped split of 9 gives on 256 CUs
-            os.environ["CM3P_G8P_GRID"] = str(grid)
+            K.gemm8p_set_grid(grid)
             os.environ["CM3P_LN_BWD_CAP"] = str(cap)
             tg, tl = timed(gemm), timed(ln)
             tc = timed(both_conc)

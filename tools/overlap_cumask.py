@@ -65,14 +65,14 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.iters
 
-    for k in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
-        os.environ.pop(k, None)
+    K.gemm8p_set_grid(0)
+    os.environ.pop("CM3P_LN_BWD_CAP", None)
     t_l = timed(ln)
     print(f"LN backward alone, whole chip: {t_l:.3f} ms", flush=True)
     for small_per16 in (2, 3, 4):  # CUs of every 16 given to the streaming kernel
         s_small, n_small = masked_stream(lambda i: i % 16 >= 16 - small_per16)
         s_big, n_big = masked_stream(lambda i: i % 16 < 16 - small_per16)
-        os.environ["CM3P_G8P_GRID"] = str(n_big)
+        K.gemm8p_set_grid(n_big)
         os.environ["CM3P_LN_BWD_CAP"] = str(n_small * 4)
         split[0] = max(8, n_big // 27)
 
@@ -86,9 +86,9 @@ def main():
 
         t_ln_small = timed(on(s_small, ln))
         for name, gemm in gemms.items():
-            os.environ.pop("CM3P_G8P_GRID")
+            K.gemm8p_set_grid(0)
             t_full = timed(gemm)
-            os.environ["CM3P_G8P_GRID"] = str(n_big)
+            K.gemm8p_set_grid(n_big)
             t_big = timed(on(s_big, gemm))
 
             def conc():

@@ -36,7 +36,22 @@ def masked_stream(pred):
     h = ctypes.c_void_p()
     rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
     assert rc == 0, rc
+    _MASKED.append(h)
     return torch.cuda.ExternalStream(h.value), n
+
+
+_MASKED: list = []  # raw handles of every CU-masked stream: destroyed before the interpreter exits (see destroy_masked_streams)
+
+
+def destroy_masked_streams():
+    """r04: `rocprofv3 --kernel-trace -- python3 tools/partition_probe.py --only chain` died with SIGSEGV in __cxa_finalize AFTER the profiler
+    had written its files (gpurun_out/r4_partition_prof.log).  The streams of hipExtStreamCreateWithCUMask were never destroyed: torch's
+    ExternalStream does not own its handle, so the masked HSA queues were still alive when libamdhip64's static destructors ran, behind
+    rocprofv3's "tool finalization" - the runtime then tears down queues the (already finalised) profiler had wrapped.  Destroying them while
+    both are alive removes the crash; the un-profiled runs behind profiles/r04_partition_probe.log never hit it."""
+    torch.cuda.synchronize()
+    while _MASKED:
+        hip.hipStreamDestroy(_MASKED.pop())
 
 
 def main():
@@ -133,8 +148,8 @@ def main():
             ts.append(e0.elapsed_time(e1))
         return min(ts), sum(ts) / len(ts)
 
-    for k in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
-        os.environ.pop(k, None)
+    K.gemm8p_set_grid(0)
+    os.environ.pop("CM3P_LN_BWD_CAP", None)
     t_ser = timed(serial) if args.only in (None, "serial") else (float("nan"), float("nan"))
     if args.only == "serial":
         return
@@ -146,7 +161,7 @@ def main():
         s_big, n_big = masked_stream(lambda i: (i // 8) < 32 - k)
 
         def grid(n):
-            os.environ["CM3P_G8P_GRID"] = str(n)
+            K.gemm8p_set_grid(n)
             os.environ["CM3P_LN_BWD_CAP"] = str(n * 4)
 
         def split():
@@ -194,9 +209,12 @@ def main():
         print(f"    {'ms per call':14s} {'whole chip':>10s} {'big mask':>10s} {'beside / as wgrad':>18s}")
         for name in pk_ser:
             print(f"    {name:14s} {pk_ser[name]:10.3f} {pk_c.get(name, float('nan')):10.3f} {pk_p.get(name, float('nan')):18.3f}", flush=True)
-        for kk in ("CM3P_G8P_GRID", "CM3P_LN_BWD_CAP"):
-            os.environ.pop(kk, None)
+        K.gemm8p_set_grid(0)
+        os.environ.pop("CM3P_LN_BWD_CAP", None)
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        destroy_masked_streams()
