@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     // One period: softmax of sub-block (tile t, query block UU) in Sc, PV of the sub-block before it, QK^T of the one after it into So.
     //   stV   slot of tile t (UU == 0: the V fragments are replaced by tile t's behind the MFMAs that read tile t-1's)
     //   stKn  slot of tile t+1 (UU == U-2: the K fragments are replaced behind the last MFMAs that read tile t's)
-    auto period = [&](auto u_c, auto slot_c, f32x16 (&Sc)[2], f32x16 (&So)[2], bool tile_ok, uint32_t w0, uint32_t w1, int t) {
+    auto period = [&](auto u_c, auto slot_c, f32x16 (&Sc)[2], f32x16 (&So)[2], int tile_bad, uint32_t w0, uint32_t w1, int t) {
         constexpr int UU = decltype(u_c)::value, UP = (UU + U - 1) % U, UN = (UU + 1) % U;
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr bool RV = UU == 0, RK = UU == U - 2;
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[0][0], __builtin_bit_cast(bf16x8, Pw[0]));
         if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(0));
-        A(So, 3, 6, lA[UP]);  // tail of the sub-block before
+        A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3 (four v_max3 each)
         A(So, 3, 7, lB[UP]);
         C2(So, 3, 1);
-        if (!tile_ok) mask_blk(Sc[0], w0);
+        if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[0], w0);
         if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(Sc[0][0], Sc[0][1], Sc[0][2]);
             mb = vmax3(Sc[0][3], Sc[0][4], Sc[0][5]);
@@ -254,16 +254,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[0][1], __builtin_bit_cast(bf16x8, Pw[0]));
         if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(1));
+        A(So, 3, 0, lA[UP]);
+        A(So, 3, 1, lB[UP]);
         if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(ma, Sc[0][10], Sc[0][11]);
             mb = vmax3(mb, Sc[0][12], Sc[0][13]);
             ma = vmax3(ma, Sc[0][14], Sc[0][15]);
         }
-        if (!tile_ok) mask_blk(Sc[1], w1);  // (two MFMAs behind the last one of this block's score chain)
+        if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[1], w1);  // (two MFMAs behind the last one of this block's score chain)
         // gap 2
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
         if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(0));
+        A(So, 3, 2, lA[UP]);
+        A(So, 3, 3, lB[UP]);
         if constexpr ((CM3P_GABL & 2) == 0) {
             mb = vmax3(mb, Sc[1][0], Sc[1][1]);
             ma = vmax3(ma, Sc[1][2], Sc[1][3]);
@@ -274,6 +278,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
         if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(1));
+        A(So, 3, 4, lA[UP]);
+        A(So, 3, 5, lB[UP]);
         if constexpr ((CM3P_GABL & 2) == 0) {
             mb = vmax3(mb, Sc[1][8], Sc[1][9]);
             ma = vmax3(ma, Sc[1][10], Sc[1][11]);
@@ -281,12 +287,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             ma = vmax3(ma, Sc[1][14], Sc[1][15]);
             const float mt = vmax3(ma, mb, mb);  // this half-wave's tile maximum, relative to the reference point
             CM3P_SB();
-            if (__any(mt > thr[UU])) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
+            if (__builtin_expect(__any(mt > thr[UU]) != 0, 0)) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
+                // Per QUERY: only a row whose own maximum asks for it moves (both half-waves of a query see the same mf and thr).  A row's
+                // result must not depend on what the other lanes of its wave hold - the rows of a padded batch that lie past a
+                // sequence's end are other data than the clamped rows of the packed batch, and a move they trigger must not shift
+                // the valid rows' reference (packed == padded bit for bit: test_attention_varlen_equals_padded_on_valid_rows).
                 const float mf = fmaxf(mt, __shfl_xor(mt, 32, 64));
                 const bool had = thr[UU] > 0.f;
-                const float shift = had ? fmaxf(mf, 0.f) : (mf > kNegInf ? mf : 0.f);
-                const float alpha = had ? __builtin_amdgcn_exp2f(-shift) : 1.0f;  // O = l = 0 before the first visible key
-                thr[UU] = mf > kNegInf ? kGDefer : thr[UU];
+                const bool move = mf > thr[UU];  // (had: mf > 2^kGDefer above the reference; !had: the row's first visible key)
+                const float shift = move ? mf : 0.f;
+                const float alpha = (move && had) ? __builtin_amdgcn_exp2f(-shift) : 1.0f;  // O = l = 0 before the first visible key
+                thr[UU] = move ? kGDefer : thr[UU];
                 ref[UU] += shift;
                 lA[UU] *= alpha;
                 lB[UU] *= alpha;
@@ -376,12 +387,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         mfma_s(So[1], Kf[1][2], qf[UN][2]);
         if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(2));
         E(Sc, 3, 3); E(Sc, 3, 4); E(Sc, 3, 5);
-        A(Sc, 3, 0, lA[UU]); A(Sc, 3, 1, lB[UU]); A(Sc, 3, 2, lA[UU]);
         CM3P_SB();
         mfma_s(So[1], Kf[1][3], qf[UN][3]);
         if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(3));
         E(Sc, 3, 6); E(Sc, 3, 7);
-        A(Sc, 3, 3, lB[UU]); A(Sc, 3, 4, lA[UU]); A(Sc, 3, 5, lB[UU]);
         C2(Sc, 3, 0);
         CM3P_SB();
     };
@@ -400,17 +409,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         if constexpr (MASK) valid = __ballot(*reinterpret_cast<const uint32_t*>(smem + SLOT * STG + 16384 + 256 * wid + 4 * lane) != 0u);
         const int rem = S - t * 64;
         if (rem < 64) valid = rem > 0 ? valid & ((1ull << rem) - 1ull) : 0ull;
-        const bool tile_ok = valid == ~0ull;
+        // (a scalar: as a bool the compiler re-derived the branch condition through a v_cndmask / v_cmp pair in every period)
+        const int tile_bad = __builtin_amdgcn_readfirstlane(valid == ~0ull ? 0 : 1);
         const unsigned long long vsh = valid >> (4 * hh);
         const uint32_t w0 = (uint32_t)vsh, w1 = (uint32_t)(vsh >> 32);
         if constexpr (U == 4) {
-            period(CM3P_IC(0), slot_c, SA, SB, tile_ok, w0, w1, t);
-            period(CM3P_IC(1), slot_c, SB, SA, tile_ok, w0, w1, t);
-            period(CM3P_IC(2), slot_c, SA, SB, tile_ok, w0, w1, t);
-            period(CM3P_IC(3), slot_c, SB, SA, tile_ok, w0, w1, t);
+            period(CM3P_IC(0), slot_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(1), slot_c, SB, SA, tile_bad, w0, w1, t);
+            period(CM3P_IC(2), slot_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(3), slot_c, SB, SA, tile_bad, w0, w1, t);
         } else {
-            period(CM3P_IC(0), slot_c, SA, SB, tile_ok, w0, w1, t);
-            period(CM3P_IC(1), slot_c, SB, SA, tile_ok, w0, w1, t);
+            period(CM3P_IC(0), slot_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(1), slot_c, SB, SA, tile_bad, w0, w1, t);
         }
     };
     // (tiles past the sequence - the trip count is rounded up to the ring - have no valid key: every score of theirs becomes -inf)
@@ -425,6 +435,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     A(SB, 3, 6, lA[U - 1]);
     A(SB, 3, 7, lB[U - 1]);
     C2(SB, 3, 1);
+    A(SB, 3, 0, lA[U - 1]);
+    A(SB, 3, 1, lB[U - 1]);
+    A(SB, 3, 2, lA[U - 1]);
+    A(SB, 3, 3, lB[U - 1]);
+    A(SB, 3, 4, lA[U - 1]);
+    A(SB, 3, 5, lB[U - 1]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         mfma_o(oacc[U - 1][0], Vf[s][0], __builtin_bit_cast(bf16x8, Pw[s]));
