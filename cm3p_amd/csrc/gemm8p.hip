@@ -377,6 +377,33 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
             const float qs = (EPI == CM3P_EPI_BF16_ROPE && nw < rope.q_cols) ? rope.q_scale : 1.f;
             uint32_t prow0 = 0;
             if constexpr (EPI == CM3P_EPI_BF16_ROPE) prow0 = rope.per_batch ? 0u : (uint32_t)mw % (uint32_t)rope.S;  // M < 2^31 (checked by the caller)
+            // rotary tables of the lane's row (row = lane >> 2 of each 16-row step, dims 8 dc .. 8 dc + 7): the rows of step i4 + 1 are
+            // requested before step i4 rotates (r05: requested where they were used, each of the eight steps of this exposed epilogue
+            // waited out an L2 round trip - the RoPE instance took 473 us where the plain one takes 291)
+            f32x4 tc0, tc1, ts0, ts1;
+            auto tab_load = [&](int i4, f32x4& c0, f32x4& c1, f32x4& s0, f32x4& s1) {
+                const int row = lane >> 2, dc = lane & 3;
+                int64_t prow;
+                if (rope.per_batch) prow = mw + i4 * 16 + row;
+                else {
+                    uint32_t x = prow0 + i4 * 16 + row;
+                    if (rope.S >= 256) x = x >= (uint32_t)rope.S ? x - (uint32_t)rope.S : x;
+                    else x %= (uint32_t)rope.S;
+                    prow = x;
+                }
+                if (!FULL && mw + i4 * 16 + row >= M) prow = 0;  // (rows past the matrix: any table row, the result is not stored)
+                const float* cr = rope.cos + prow * 32 + dc * 8;
+                const float* sr = rope.sin + prow * 32 + dc * 8;
+                if constexpr (CM3P_G8P_ABL & 128) {
+                    asm volatile("" : "=v"(c0), "=v"(c1), "=v"(s0), "=v"(s1) : "v"(cr), "v"(sr));
+                } else {
+                    c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+                    s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
+                }
+            };
+            if constexpr (EPI == CM3P_EPI_BF16_ROPE) {
+                if (rotate) tab_load(0, tc0, tc1, ts0, ts1);
+            }
 #pragma unroll
             for (int i4 = 0; i4 < 8; ++i4) {
                 char* eb = ebuf + (i4 & 1) * 2048;
@@ -400,24 +427,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const uint16_t* __restri
                     char* pb = eb + row * 128 + (((dc + 4) ^ (row & 7)) << 4);
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(pa);
                     const u32x4 xb = *reinterpret_cast<const u32x4*>(pb);
-                    if (FULL || mw + i4 * 16 + row < M) {
-                        int64_t prow;
-                        if (rope.per_batch) prow = mw + i4 * 16 + row;
-                        else {
-                            uint32_t x = prow0 + i4 * 16 + row;
-                            if (rope.S >= 256) x = x >= (uint32_t)rope.S ? x - (uint32_t)rope.S : x;
-                            else x %= (uint32_t)rope.S;
-                            prow = x;
-                        }
-                        const float* cr = rope.cos + prow * 32 + dc * 8;
-                        const float* sr = rope.sin + prow * 32 + dc * 8;
-                        f32x4 c0, c1, s0, s1;
-                        if constexpr (CM3P_G8P_ABL & 128) {
-                            asm volatile("" : "=v"(c0), "=v"(c1), "=v"(s0), "=v"(s1) : "v"(cr), "v"(sr));
-                        } else {
-                            c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
-                            s0 = *reinterpret_cast<const f32x4*>(sr), s1 = *reinterpret_cast<const f32x4*>(sr + 4);
-                        }
+                    const f32x4 c0 = tc0, c1 = tc1, s0 = ts0, s1 = ts1;
+                    if (i4 < 7) tab_load(i4 + 1, tc0, tc1, ts0, ts1);
+                    {
                         const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                         const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
                         u32x4 oa, ob;
