@@ -40,7 +40,7 @@ namespace {
 
 constexpr int kGSlots = 4;
 constexpr int kGStageNoMask = 16384;          // K image (row fragments) + V image (transposed reads)
-constexpr int kGStageMask = 16384 + 4 * 256;  // + one validity dword per key, a private copy per wave
+constexpr int kGStageMask = 16384 + 4 * 256;  // + one validity dword per key, a private copy per wave (the MASK instance adds 32 bytes behind the ring)
 constexpr float kGDefer = 6.0f;
 
 #define CM3P_IC(n) std::integral_constant<int, (n)> {}
@@ -90,6 +90,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
     const int NT = (S + 63) / 64;
+    // The sweep's two parts (see the loops below): [0, t_fast) tiles whose keys are all visible, t_fast a multiple of the ring; [t_fast,
+    // t_end) the rest up to the tile of the last visible key.  With a key mask the workgroup scans its batch row's S bytes once.
+    int first_bad = S % 64 ? S / 64 : NT, t_end = NT;
+    if constexpr (MASK) {
+        const uint8_t* kmr = kmask + sv.row0;
+        int fz = INT_MAX, lnz = -1;  // first zero byte, last non-zero byte of this thread's share (16 consecutive bytes per 4 KiB of the row;
+        for (int base = 0; base < S; base += 4096) {  // sixteen independent byte loads per trip: one round trip, not sixteen)
+            uint8_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = kmr[min(base + tid * 16 + j, S - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = base + tid * 16 + j;
+                if (i < S) {
+                    fz = (v[j] == 0 && i < fz) ? i : fz;
+                    lnz = v[j] != 0 ? i : lnz;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            fz = min(fz, __shfl_xor(fz, o, 64));
+            lnz = max(lnz, __shfl_xor(lnz, o, 64));
+        }
+        int* red = reinterpret_cast<int*>(smem + kGSlots * kGStageMask);  // 8 ints behind the ring
+        if (lane == 0) {
+            red[wid] = fz;
+            red[4 + wid] = lnz;
+        }
+        __syncthreads();
+        fz = min(min(red[0], red[1]), min(red[2], red[3]));
+        lnz = max(max(red[4], red[5]), max(red[6], red[7]));
+        first_bad = min(first_bad, fz / 64);  // (INT_MAX / 64 is far past NT)
+        t_end = lnz < 0 ? 0 : lnz / 64 + 1;
+    }
+    const int t_fast = min(first_bad, t_end) & ~3;
 
     // ---- tile DMA: wave w brings rows 16 w .. 16 w + 15 of K and of V (two 1-KiB pieces each) and, with a mask, its own copy of the
     // tile's 64 validity bytes as dwords.  Rows are clamped to the sequence, so tiles past it (the ring runs three ahead) read valid memory.
@@ -229,7 +265,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     // One period: softmax of sub-block (tile t, query block UU) in Sc, PV of the sub-block before it, QK^T of the one after it into So.
     //   stV   slot of tile t (UU == 0: the V fragments are replaced by tile t's behind the MFMAs that read tile t-1's)
     //   stKn  slot of tile t+1 (UU == U-2: the K fragments are replaced behind the last MFMAs that read tile t's)
-    auto period = [&](auto u_c, auto slot_c, f32x16 (&Sc)[2], f32x16 (&So)[2], int tile_bad, uint32_t w0, uint32_t w1, int t) {
+    auto period = [&](auto u_c, auto slot_c, auto fast_c, f32x16 (&Sc)[2], f32x16 (&So)[2], int tile_bad, uint32_t w0, uint32_t w1, int t) {
+        constexpr bool FAST = decltype(fast_c)::value != 0;  // (the sweep's first part: every key of every tile visible, no masking code at all)
         constexpr int UU = decltype(u_c)::value, UP = (UU + U - 1) % U, UN = (UU + 1) % U;
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr bool RV = UU == 0, RK = UU == U - 2;
@@ -243,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3 (four v_max3 each)
         A(So, 3, 7, lB[UP]);
         C2(So, 3, 1);
-        if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[0], w0);
+        if constexpr (!FAST)
+            if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[0], w0);
         if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(Sc[0][0], Sc[0][1], Sc[0][2]);
             mb = vmax3(Sc[0][3], Sc[0][4], Sc[0][5]);
@@ -261,7 +299,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             mb = vmax3(mb, Sc[0][12], Sc[0][13]);
             ma = vmax3(ma, Sc[0][14], Sc[0][15]);
         }
-        if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[1], w1);  // (two MFMAs behind the last one of this block's score chain)
+        if constexpr (!FAST)
+            if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[1], w1);  // (two MFMAs behind the last one of this block's score chain)
         // gap 2
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
@@ -396,39 +435,56 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     };
 
     // ---- the key sweep, four tiles (= the ring) per trip so that a tile's slot is a compile-time constant ---------------------------
-    auto tile = [&](auto slot_c, int t) {
+    auto tile = [&](auto slot_c, auto fast_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value != 0;
         // tiles <= t + 1 of this wave have landed (only tile t + 2 may be in flight); behind the barrier: of every wave, and every
         // wave has finished with the slot of tile t - 1, which the DMAs of tile t + 3 overwrite
         if constexpr (MASK) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr ((CM3P_GABL & 16) == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // validity of the tile's keys: wave-uniform 64 bits (bit k = key 64 t + k may be seen)
-        unsigned long long valid = ~0ull;
-        if constexpr (MASK) valid = __ballot(*reinterpret_cast<const uint32_t*>(smem + SLOT * STG + 16384 + 256 * wid + 4 * lane) != 0u);
-        const int rem = S - t * 64;
-        if (rem < 64) valid = rem > 0 ? valid & ((1ull << rem) - 1ull) : 0ull;
-        // (a scalar: as a bool the compiler re-derived the branch condition through a v_cndmask / v_cmp pair in every period)
-        const int tile_bad = __builtin_amdgcn_readfirstlane(valid == ~0ull ? 0 : 1);
-        const unsigned long long vsh = valid >> (4 * hh);
-        const uint32_t w0 = (uint32_t)vsh, w1 = (uint32_t)(vsh >> 32);
+        int tile_bad = 0;
+        uint32_t w0 = ~0u, w1 = ~0u;
+        if constexpr (!FAST) {
+            // validity of the tile's keys: wave-uniform 64 bits (bit k = key 64 t + k may be seen)
+            unsigned long long valid = ~0ull;
+            if constexpr (MASK) valid = __ballot(*reinterpret_cast<const uint32_t*>(smem + SLOT * STG + 16384 + 256 * wid + 4 * lane) != 0u);
+            const int rem = S - t * 64;
+            if (rem < 64) valid = rem > 0 ? valid & ((1ull << rem) - 1ull) : 0ull;
+            // (a scalar: as a bool the compiler re-derived the branch condition through a v_cndmask / v_cmp pair in every period)
+            tile_bad = __builtin_amdgcn_readfirstlane(valid == ~0ull ? 0 : 1);
+            const unsigned long long vsh = valid >> (4 * hh);
+            w0 = (uint32_t)vsh, w1 = (uint32_t)(vsh >> 32);
+        }
         if constexpr (U == 4) {
-            period(CM3P_IC(0), slot_c, SA, SB, tile_bad, w0, w1, t);
-            period(CM3P_IC(1), slot_c, SB, SA, tile_bad, w0, w1, t);
-            period(CM3P_IC(2), slot_c, SA, SB, tile_bad, w0, w1, t);
-            period(CM3P_IC(3), slot_c, SB, SA, tile_bad, w0, w1, t);
+            period(CM3P_IC(0), slot_c, fast_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(1), slot_c, fast_c, SB, SA, tile_bad, w0, w1, t);
+            period(CM3P_IC(2), slot_c, fast_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(3), slot_c, fast_c, SB, SA, tile_bad, w0, w1, t);
         } else {
-            period(CM3P_IC(0), slot_c, SA, SB, tile_bad, w0, w1, t);
-            period(CM3P_IC(1), slot_c, SB, SA, tile_bad, w0, w1, t);
+            period(CM3P_IC(0), slot_c, fast_c, SA, SB, tile_bad, w0, w1, t);
+            period(CM3P_IC(1), slot_c, fast_c, SB, SA, tile_bad, w0, w1, t);
         }
     };
-    // (tiles past the sequence - the trip count is rounded up to the ring - have no valid key: every score of theirs becomes -inf)
-    for (int t = 0; t < NT; t += 4) {
-        tile(CM3P_IC(0), t);
-        tile(CM3P_IC(1), t + 1);
-        tile(CM3P_IC(2), t + 2);
-        tile(CM3P_IC(3), t + 3);
+    // Two loops, one after the other: the tiles in front of the first key some lane may not see run a stream WITHOUT masking code (a
+    // not-taken branch in front of each block's maximum costs 4 %: two per period; timing-only build without them 3.00 -> 2.88 ms at
+    // C4), the rest - from the ring-aligned tile of the first invisible key to the tile of the last visible one - the stream with one
+    // branch per block.  Tiles behind the last visible key are not visited at all: every score of theirs would be -inf, p = 0.
+    // (Both copies inside ONE loop behind an if / else per tile made hipcc spill 1500 registers: the copies must not meet in a phi.)
+    int t = 0;
+    for (; t < t_fast; t += 4) {
+        tile(CM3P_IC(0), CM3P_IC(1), t);
+        tile(CM3P_IC(1), CM3P_IC(1), t + 1);
+        tile(CM3P_IC(2), CM3P_IC(1), t + 2);
+        tile(CM3P_IC(3), CM3P_IC(1), t + 3);
+    }
+    // (tiles past t_end - the trip count is rounded up to the ring - have no visible key: every score of theirs becomes -inf)
+    for (; t < t_end; t += 4) {
+        tile(CM3P_IC(0), CM3P_IC(0), t);
+        tile(CM3P_IC(1), CM3P_IC(0), t + 1);
+        tile(CM3P_IC(2), CM3P_IC(0), t + 2);
+        tile(CM3P_IC(3), CM3P_IC(0), t + 3);
     }
 
     // ---- drain: the tail and the PV of the last sub-block (query block U-1; its scores are in SB)
@@ -476,11 +532,11 @@ int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const ui
     static Cm3pDevOnce once;  // (per device: common.h)
     const int rc_once = once.run([] {
         return cm3p_set_max_lds({reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, true>), reinterpret_cast<const void*>(&attn_fwd_g_kernel<U, false>)},
-                                kGSlots * kGStageMask);
+                                kGSlots * kGStageMask + 32);
     });
     if (rc_once != CM3P_OK) return rc_once;
     if (key_mask)
-        attn_fwd_g_kernel<U, true><<<grid, 256, kGSlots * kGStageMask, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, vl);
+        attn_fwd_g_kernel<U, true><<<grid, 256, kGSlots * kGStageMask + 32, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, key_mask, S, nh, vl);
     else
         attn_fwd_g_kernel<U, false><<<grid, 256, kGSlots * kGStageNoMask, s>>>((const uint16_t*)qkv, (uint16_t*)out, lse, nullptr, S, nh, vl);
     if (hipGetLastError() != hipSuccess) return CM3P_ERR_LAUNCH;

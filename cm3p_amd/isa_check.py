@@ -168,31 +168,34 @@ def check_attention_fwd(isa: str):
         bodies = kernel_bodies(isa, "attn_fwd_g_kernelILi4ELb%dE" % int(mask))
         _need(len(bodies) == 1, f"attn_fwd_g_kernel<4, {mask}>: {len(bodies)} instances")
         sym, body = next(iter(bodies.items()))
-        ring = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_32x32x16_bf16") == 256]
-        _need(ring, f"{sym}: four-tile loop (256 MFMAs) not found")
-        ring = ring[-1]
+        rings = [seg for _, seg in loops(body) if seg.count("v_mfma_f32_32x32x16_bf16") == 256]
+        _need(len(rings) == 2, f"{sym}: {len(rings)} four-tile loops (256 MFMAs) found, expected the all-visible sweep and the masked sweep")
         nd = "5" if mask else "4"
-        _need(ring.count("global_load_lds_dwordx4") == 16 and ring.count("global_load_lds_ubyte") == (4 if mask else 0), f"{sym}: LDS-DMA count per loop trip changed")
-        _need(len(re.findall(r"\bglobal_(load|store|atomic)_", ring)) == 16 + (4 if mask else 0) and not re.search(r"\bbuffer_|\bflat_|scratch_", ring),
-              f"{sym}: stray vector-memory instruction in the loop")
-        _need(ring.count("s_barrier") == 4, f"{sym}: {ring.count('s_barrier')} barriers per loop trip, expected 4")
-        _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == [nd] * 4, f"{sym}: the loop's vector-memory waits are not four vmcnt({nd})")
-        for m in re.finditer(r"s_waitcnt vmcnt\(\d+\)", ring):
-            _need(re.match(r"\s*s_barrier", ring[m.end():]), f"{sym}: a counted wait is not directly in front of its barrier")
-        _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], a\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\]", ring)) == 128, f"{sym}: score MFMA form (VGPR result, AGPR operands)")
-        _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1", ring)) == 128, f"{sym}: output MFMA form (AGPR accumulator tied to itself)")
-        # the hot path of the loop trip
         lines = body.split("\n")
-        first = body[:body.index(ring)].count("\n")
-        hot = [l.split()[0] for _, l in hot_path(lines, first, first + ring.count("\n")) if l.startswith("\t") and l.split()]
-        n_mfma = sum(o.startswith("v_mfma") for o in hot)
-        _need(n_mfma == 256, f"{sym}: {n_mfma} MFMAs on the hot path of a loop trip")
-        _need(sum(o.startswith("v_exp_f32") for o in hot) == 512, f"{sym}: exponentials on the hot path")
-        vec = sum(o.startswith("v_") and not o.startswith("v_mfma") for o in hot)
-        _need(vec <= 110 * 16, f"{sym}: {vec / 16:.1f} vector instructions per 16 MFMAs on the hot path (bound: 110)")
-        acc = sum("accvgpr" in o for o in hot)
-        _need(acc <= 32, f"{sym}: {acc} accumulator copies on the hot path of a loop trip (the loop header's block is 32)")
-        _need(sum(o.startswith("v_mov_b32") for o in hot) <= 8, f"{sym}: v_mov on the hot path")
+        for which, ring in enumerate(rings):  # 0: every key visible (no masking code), 1: one branch per block
+            what = f"{sym} loop {which}"
+            _need(ring.count("global_load_lds_dwordx4") == 16 and ring.count("global_load_lds_ubyte") == (4 if mask else 0), f"{what}: LDS-DMA count per loop trip changed")
+            _need(len(re.findall(r"\bglobal_(load|store|atomic)_", ring)) == 16 + (4 if mask else 0) and not re.search(r"\bbuffer_|\bflat_|scratch_", ring),
+                  f"{what}: stray vector-memory instruction in the loop")
+            _need(ring.count("s_barrier") == 4, f"{what}: {ring.count('s_barrier')} barriers per loop trip, expected 4")
+            _need(re.findall(r"s_waitcnt vmcnt\((\d+)\)", ring) == [nd] * 4, f"{what}: the loop's vector-memory waits are not four vmcnt({nd})")
+            for m in re.finditer(r"s_waitcnt vmcnt\(\d+\)", ring):
+                _need(re.match(r"\s*s_barrier", ring[m.end():]), f"{what}: a counted wait is not directly in front of its barrier")
+            _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], a\[\d+:\d+\], a\[\d+:\d+\], v\[\d+:\d+\]", ring)) == 128, f"{what}: score MFMA form (VGPR result, AGPR operands)")
+            _need(len(re.findall(r"v_mfma_f32_32x32x16_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1", ring)) == 128, f"{what}: output MFMA form (AGPR accumulator tied to itself)")
+            # the hot path of the loop trip
+            first = body[:body.index(ring)].count("\n")
+            hot = [l.split()[0] for _, l in hot_path(lines, first, first + ring.count("\n")) if l.startswith("\t") and l.split()]
+            n_mfma = sum(o.startswith("v_mfma") for o in hot)
+            _need(n_mfma == 256, f"{what}: {n_mfma} MFMAs on the hot path of a loop trip")
+            _need(sum(o.startswith("v_exp_f32") for o in hot) == 512, f"{what}: exponentials on the hot path")
+            vec = sum(o.startswith("v_") and not o.startswith("v_mfma") for o in hot)
+            _need(vec <= 110 * 16, f"{what}: {vec / 16:.1f} vector instructions per 16 MFMAs on the hot path (bound: 110)")
+            acc = sum("accvgpr" in o for o in hot)
+            _need(acc <= 32, f"{what}: {acc} accumulator copies on the hot path of a loop trip (the loop header's block is 32)")
+            _need(sum(o.startswith("v_mov_b32") for o in hot) <= 8, f"{what}: v_mov on the hot path")
+            nbr = sum(o.startswith("s_cbranch") for o in hot)
+            _need(nbr <= (17 if which == 0 else 49), f"{what}: {nbr} conditional branches on the hot path (all-visible sweep: one per period + the loop's)")
         _need(body.count("s_waitcnt vmcnt(0)") >= 2, f"{sym}: the prologue wait / the final drain of the ring is missing")
 
 
