@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[0][0], __builtin_bit_cast(bf16x8, Pw[0]));
         if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(0));
-        A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3 (four v_max3 each)
+        A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3
         A(So, 3, 7, lB[UP]);
         C2(So, 3, 1);
         if constexpr (!FAST)
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             mb = vmax3(Sc[0][3], Sc[0][4], Sc[0][5]);
             ma = vmax3(ma, Sc[0][6], Sc[0][7]);
             mb = vmax3(mb, Sc[0][8], Sc[0][9]);
+            ma = vmax3(ma, Sc[0][10], Sc[0][11]);
         }
         // gap 1
         CM3P_SB();
@@ -294,39 +295,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(1));
         A(So, 3, 0, lA[UP]);
         A(So, 3, 1, lB[UP]);
-        if constexpr ((CM3P_GABL & 2) == 0) {
-            ma = vmax3(ma, Sc[0][10], Sc[0][11]);
-            mb = vmax3(mb, Sc[0][12], Sc[0][13]);
-            ma = vmax3(ma, Sc[0][14], Sc[0][15]);
-        }
         if constexpr (!FAST)
             if (__builtin_expect(tile_bad != 0, 0)) mask_blk(Sc[1], w1);  // (two MFMAs behind the last one of this block's score chain)
+        if constexpr ((CM3P_GABL & 2) == 0) {
+            mb = vmax3(mb, Sc[0][12], Sc[0][13]);
+            ma = vmax3(ma, Sc[0][14], Sc[0][15]);
+            mb = vmax3(mb, Sc[1][0], Sc[1][1]);
+            ma = vmax3(ma, Sc[1][2], Sc[1][3]);
+        }
         // gap 2
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
         if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(0));
-        A(So, 3, 2, lA[UP]);
-        A(So, 3, 3, lB[UP]);
         if constexpr ((CM3P_GABL & 2) == 0) {
-            mb = vmax3(mb, Sc[1][0], Sc[1][1]);
-            ma = vmax3(ma, Sc[1][2], Sc[1][3]);
             mb = vmax3(mb, Sc[1][4], Sc[1][5]);
             ma = vmax3(ma, Sc[1][6], Sc[1][7]);
-        }
-        // gap 3
-        CM3P_SB();
-        mfma_o(oacc[UP][1], Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
-        if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(1));
-        A(So, 3, 4, lA[UP]);
-        A(So, 3, 5, lB[UP]);
-        if constexpr ((CM3P_GABL & 2) == 0) {
             mb = vmax3(mb, Sc[1][8], Sc[1][9]);
             ma = vmax3(ma, Sc[1][10], Sc[1][11]);
             mb = vmax3(mb, Sc[1][12], Sc[1][13]);
+        }
+        // gap 3: the last of the maximum, the wave-uniform decision, THEN four row-sum adds, then the branch: a branch right behind the
+        // compare that feeds it waits out the VALU -> scalar round trip with nothing to issue
+        CM3P_SB();
+        mfma_o(oacc[UP][1], Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
+        if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(1));
+        if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(ma, Sc[1][14], Sc[1][15]);
             const float mt = vmax3(ma, mb, mb);  // this half-wave's tile maximum, relative to the reference point
+            const unsigned long long any_move = __ballot(mt > thr[UU]);
+            asm volatile("" ::"s"(any_move));
+            CM3P_SB();  // (the compare stays in front of the adds: pure VALU work floats across a pin, not across this)
+            A(So, 3, 2, lA[UP]);
+            A(So, 3, 3, lB[UP]);
+            A(So, 3, 4, lA[UP]);
+            A(So, 3, 5, lB[UP]);
             CM3P_SB();
-            if (__builtin_expect(__any(mt > thr[UU]) != 0, 0)) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
+            if (__builtin_expect(any_move != 0ull, 0)) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
                 // Per QUERY: only a row whose own maximum asks for it moves (both half-waves of a query see the same mf and thr).  A row's
                 // result must not depend on what the other lanes of its wave hold - the rows of a padded batch that lie past a
                 // sequence's end are other data than the clamped rows of the packed batch, and a move they trigger must not shift
@@ -360,6 +364,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
                     negref[UU][i] = nv;
                 }
             }
+        } else {
+            A(So, 3, 2, lA[UP]);
+            A(So, 3, 3, lB[UP]);
+            A(So, 3, 4, lA[UP]);
+            A(So, 3, 5, lB[UP]);
         }
         // gaps 4-6: chunk 0
         CM3P_SB();
