@@ -733,7 +733,7 @@ def test_audio_conv_frontend_matches_conv1d(K):
 def test_pipelined_global_forward_agrees_with_the_three_wave_kernel(K, monkeypatch, S, lens, nh):
     """Global layers with pre-scaled q have two forward implementations behind one call: the software-pipelined one-wave-per-SIMD kernel
     (attention_fwd.hip, the default) and attn_fwd_kernel (attention.hip, CM3P_ATTN_FWD_IMPL=wave3).  Same mathematics, different order
-    of the row sums and a different moment at which the lazily moved reference point moves: outputs agree to bf16 rounding, lse to
+    of the row sums and a different moment at which the lazily moved reference point moves: outputs agree to two bf16 roundings, lse to
     fp32 rounding, rows without a visible key are exact zeros / +inf in both, and the pipelined kernel is bit-reproducible."""
     g = torch.Generator().manual_seed(S + nh)
     B = 2 if lens is None else len(lens)
@@ -756,9 +756,11 @@ def test_pipelined_global_forward_agrees_with_the_three_wave_kernel(K, monkeypat
     assert (l1[fin] - l3[fin]).abs().max().item() <= 2e-5
     if (~fin).any():
         assert bool((l1[~fin] == float("inf")).all())
-    # one bf16 rounding apart at most (plus the fp32 reassociation of a 64-term dot product)
+    # two bf16 roundings apart at most.  The kernels round P to bf16 relative to DIFFERENT reference points (the pipelined one moves a row's
+    # reference when that row asks, attn_fwd_kernel when any row of the wave does), so a different subset of the p values rounds up:
+    # a relative difference of up to ~2^-8 between the fp32 results, i.e. one or two units of the bf16 output
     d = (o1.float() - o3.float()).abs()
-    assert (d <= 0.0079 * o3.float().abs() + 2e-3).all(), d.max().item()
+    assert (d <= 2 * 0.0079 * o3.float().abs() + 3e-3).all(), d.max().item()
 
 
 @pytest.mark.parametrize("nkb,lens", [(1, None), (2, [512 - 17, 300]), (3, None), (5, [1280 - 100, 1025, 300])])
