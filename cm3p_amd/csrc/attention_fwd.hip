@@ -10,10 +10,10 @@
 // file, and a wave owns U = 4 blocks of 32 queries (128 queries; the workgroup 512).  Its stream is a chain of "periods", one per
 // (key tile, query block) = sub-block j; period j issues 16 MFMAs - the 8 of PV(j-1), then the 8 of QK^T(j+1) - and between
 // them, a few instructions per MFMA gap and placed by hand (sched_barrier chunks), the softmax arithmetic of sub-block j:
-//     gaps 0-3   the tail of sub-block j-1 (two adds, two packs), 16 v_max3 over the 32 scores of the lane; then the wave-uniform
-//                decision whether any reference point must move (rare: the cold block behind it rescales O, l, the scores and
-//                rewrites the 16-register -ref operand of that query block)
-//     gaps 4-15  32 v_exp, 32 v_add (two partial row sums per query block), 16 v_cvt_pk, three gaps per 8-score chunk
+//     gaps 0-3   the tail of sub-block j-1 (eight row-sum adds, two packs), 16 v_max3 over the 32 scores of the lane; then the
+//                wave-uniform decision whether any row's reference point must move - compare, four of the adds, then the branch (rare:
+//                the cold block behind it rescales O, l, the scores and rewrites the 16-register -ref operand, per query row)
+//     gaps 4-15  32 v_exp, 24 v_add (two partial row sums per query block), 16 v_cvt_pk, three gaps per 8-score chunk
 // so a sub-block's scores are produced a period before they are needed and consumed a period after, and no MFMA result is read
 // before 2 further MFMAs have been issued (hipcc pads no hazard for the inline-asm MFMAs that deliver the scores to VGPRs).
 // Per 16 MFMAs the stream carries 97 VALU instructions (the old kernel: 155): no v_mov re-splats -ref (it is a persistent C
@@ -24,8 +24,9 @@
 // K / V tiles (64 keys): LDS-DMA (TileDma, attn_common.h) into a ring of 4 slots, three tiles ahead; ONE workgroup barrier per
 // tile behind ONE counted s_waitcnt vmcnt (every wave issues exactly 4 - with a key mask 5 - DMAs per tile, unconditionally, rows
 // clamped to the sequence: tests/test_kernel_isa.py pins the pattern).  Key validity (padding mask, keys past the sequence) is
-// a 64-bit wave-uniform word per tile; a tile whose keys are all valid - every tile of an unpadded batch but the last - runs
-// the stream above unchanged, any other pays three VALU instructions per score in a cold block.
+// a 64-bit wave-uniform word per tile.  The sweep is TWO loops: the tiles in front of the first key some lane may not see run
+// the stream above with no masking code at all (a not-taken branch per block costs 4 %), the rest - up to the tile of the last
+// visible key; tiles behind it are not visited - a copy with one branch per block in front of three VALU instructions per score.
 #include <stdlib.h>
 
 #include <type_traits>
