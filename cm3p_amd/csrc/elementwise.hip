@@ -180,63 +180,124 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(uint16_t* __restrict__ 
 }
 
 // ---- GeGLU / GELU -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ h, uint16_t* __restrict__ g, int64_t T, int I) {
-    // item i = (row t, 16-byte chunk c) with i = t * c8 + c, walked with the grid's stride; the (t, c) pair is advanced by the
-    // stride's quotient and remainder instead of a 64-bit division per item
-    const int c8 = I / 8;
-    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t dq = stride / c8;
-    const int dr = (int)(stride % c8);
-    int64_t t = i0 / c8;
-    int c = (int)(i0 % c8);
-    for (; t < T; t += dq, c += dr) {
-        if (c >= c8) {
-            c -= c8;
-            if (++t >= T) break;
-        }
-        float a[8], b[8], y[8];
-        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
-        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const f32x2 gl = gelu_erf2(f32x2{a[j], a[j + 1]});
-            y[j] = gl.x * b[j];
-            y[j + 1] = gl.y * b[j + 1];
-        }
-        gstore16<(CM3P_NT & 16) != 0>(g + t * I + c * 8, pack8(y));
+#ifndef CM3P_GEGLU_X2
+#define CM3P_GEGLU_X2 3  // extra items per lane and trip - 3: a wave walks 4 KiB of every stream per trip (0: 1 KiB, r01-r04)
+#endif
+// The lane's items of one trip: a wave's 64 NI consecutive items i = t * c8 + c, lane l taking base + l, base + 64 + l, ...: every load / store
+// of a trip is one contiguous KiB per wave and a wave streams NI KiB of every row segment before it moves on (r05: with 1 KiB per stream
+// and trip the GeGLU kernels' three to five streams ran at 5.0 TB/s where LayerNorm's 3-KiB rows reach 6.2; 4 KiB: backward 296 -> 275 us).
+// (t, c) advances by the stride's quotient and remainder: no 64-bit division per item.
+template <int NI>
+struct GegluWalk {
+    int64_t dq, t0;
+    int dr, c0, c8;
+    __device__ __forceinline__ GegluWalk(int I) {
+        c8 = I / 8;
+        const int64_t stride = (int64_t)gridDim.x * 256 * NI, first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * NI) + (threadIdx.x & 63);
+        dq = stride / c8;
+        dr = (int)(stride % c8);
+        t0 = first / c8;
+        c0 = (int)(first % c8);
     }
+    // -> false when the walk is over; else the NI items of this trip (items past the end repeat item 0 and are flagged)
+    __device__ __forceinline__ bool next(int64_t T, int64_t (&tt)[NI], int (&cc)[NI], bool (&ok)[NI]) {
+        if (t0 >= T) return false;
+        if (c0 >= c8) {
+            c0 -= c8;
+            if (++t0 >= T) return false;
+        }
+        tt[0] = t0, cc[0] = c0, ok[0] = true;
+#pragma unroll
+        for (int k = 1; k < NI; ++k) {
+            tt[k] = tt[k - 1];
+            cc[k] = cc[k - 1] + 64;
+            while (cc[k] >= c8) {
+                cc[k] -= c8;
+                ++tt[k];
+            }
+            ok[k] = tt[k] < T;
+            if (!ok[k]) tt[k] = t0, cc[k] = c0;
+        }
+        t0 += dq;
+        c0 += dr;
+        return true;
+    }
+};
+
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ h, uint16_t* __restrict__ g, int64_t T, int I) {
+    constexpr int NI = CM3P_GEGLU_X2 + 1;
+    GegluWalk<NI> walk(I);
+    int64_t tt[NI];
+    int cc[NI];
+    bool ok[NI];
+    while (walk.next(T, tt, cc, ok)) {
+        uint4 ha[NI], hb[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            ha[k] = gload16<(CM3P_NT & 128) != 0>(h + tt[k] * 2 * I + cc[k] * 8);
+            hb[k] = gload16<(CM3P_NT & 128) != 0>(h + tt[k] * 2 * I + I + cc[k] * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            float a[8], b[8], y[8];
+            unpack8(ha[k], a);
+            unpack8(hb[k], b);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 gl = gelu_erf2(f32x2{a[j], a[j + 1]});
+                y[j] = gl.x * b[j];
+                y[j + 1] = gl.y * b[j + 1];
+            }
+            if (ok[k]) gstore16<(CM3P_NT & 16) != 0>(g + tt[k] * I + cc[k] * 8, pack8(y));
+        }
+    }
+}
+
+// one item of the GeGLU backward: 8 columns of one row
+__device__ __forceinline__ void geglu_bwd_item(const uint4 ha, const uint4 hb, const uint4 hd, uint4& oa, uint4& ob) {
+    float a[8], b[8], d[8], da[8], db[8];
+    unpack8(ha, a);
+    unpack8(hb, b);
+    unpack8(hd, d);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {  // gelu'(a) = Phi(a) + a phi(a), gelu(a) = a Phi(a): one Phi for both
+        const f32x2 av = {a[j], a[j + 1]};
+        f32x2 cdf, pdf;
+        gelu_cdf_pdf2(av, cdf, pdf);
+        const f32x2 gr = av * pdf + cdf, gl = av * cdf;
+        da[j] = d[j] * b[j] * gr.x;
+        da[j + 1] = d[j + 1] * b[j + 1] * gr.y;
+        db[j] = d[j] * gl.x;
+        db[j + 1] = d[j + 1] * gl.y;
+    }
+    oa = pack8(da);
+    ob = pack8(db);
 }
 
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ dg, const uint16_t* __restrict__ h,
                                                         uint16_t* __restrict__ dh, int64_t T, int I) {
-    const int c8 = I / 8;  // (item walk: see geglu_fwd_kernel)
-    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t dq = stride / c8;
-    const int dr = (int)(stride % c8);
-    int64_t t = i0 / c8;
-    int c = (int)(i0 % c8);
-    for (; t < T; t += dq, c += dr) {
-        if (c >= c8) {
-            c -= c8;
-            if (++t >= T) break;
-        }
-        float a[8], b[8], d[8], da[8], db[8];
-        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + c * 8), a);
-        unpack8(gload16<(CM3P_NT & 128) != 0>(h + t * 2 * I + I + c * 8), b);
-        unpack8(gload16<(CM3P_NT & 128) != 0>(dg + t * I + c * 8), d);
+    constexpr int NI = CM3P_GEGLU_X2 + 1;
+    GegluWalk<NI> walk(I);
+    int64_t tt[NI];
+    int cc[NI];
+    bool ok[NI];
+    while (walk.next(T, tt, cc, ok)) {
+        uint4 ha[NI], hb[NI], hd[NI];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {  // gelu'(a) = Phi(a) + a phi(a), gelu(a) = a Phi(a): one Phi for both
-            const f32x2 av = {a[j], a[j + 1]};
-            f32x2 cdf, pdf;
-            gelu_cdf_pdf2(av, cdf, pdf);
-            const f32x2 gr = av * pdf + cdf, gl = av * cdf;
-            da[j] = d[j] * b[j] * gr.x;
-            da[j + 1] = d[j + 1] * b[j + 1] * gr.y;
-            db[j] = d[j] * gl.x;
-            db[j + 1] = d[j + 1] * gl.y;
+        for (int k = 0; k < NI; ++k) {
+            ha[k] = gload16<(CM3P_NT & 128) != 0>(h + tt[k] * 2 * I + cc[k] * 8);
+            hb[k] = gload16<(CM3P_NT & 128) != 0>(h + tt[k] * 2 * I + I + cc[k] * 8);
+            hd[k] = gload16<(CM3P_NT & 128) != 0>(dg + tt[k] * I + cc[k] * 8);
         }
-        gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + c * 8, pack8(da));
-        gstore16<(CM3P_NT & 16) != 0>(dh + t * 2 * I + I + c * 8, pack8(db));
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            uint4 oa, ob;
+            geglu_bwd_item(ha[k], hb[k], hd[k], oa, ob);
+            if (ok[k]) {
+                gstore16<(CM3P_NT & 16) != 0>(dh + tt[k] * 2 * I + cc[k] * 8, oa);
+                gstore16<(CM3P_NT & 16) != 0>(dh + tt[k] * 2 * I + I + cc[k] * 8, ob);
+            }
+        }
     }
 }
 

@@ -255,7 +255,11 @@ def cast_bf16_with_transpose_many(ws: list) -> list:
         out.append((y, yt))
         off += 2 * rows * cols
         blocks += (-(-rows // 64)) * (-(-cols // 64))
-    tab = torch.tensor(table, dtype=torch.int64).to(dev, non_blocking=True)
+    # The table goes through PINNED host memory: torch's caching host allocator keeps a pinned block out of circulation until the copy
+    # that reads it has run, so the asynchronous upload cannot race the temporary's release (r04 advisor: from a pageable temporary that
+    # is freed on return, HIP is free to pin and copy lazily - the kernel would then dereference garbage addresses).  A blocking copy would
+    # be safe too but makes the host wait for the stream, and the host runs two to three steps ahead of the GPU (tools/host_lead.py).
+    tab = torch.tensor(table, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
     call("cm3p_cast_f32_bf16_t_multi", ptr(tab, torch.int64), len(ws), blocks, stream(), work=8.0 * numel)
     return out
 
