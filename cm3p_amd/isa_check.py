@@ -1,7 +1,7 @@
 """Compile-time checks of the generated ISA for the kernels whose CORRECTNESS depends on what hipcc emits (no GPU needed).
 
-Three files synchronise LDS-DMA rings with counted `s_waitcnt vmcnt(N)` and / or issue inline-asm MFMAs that hipcc pads no
-hazards for: attention_bwd.hip, attention_bwd_fused.hip and gemm8p.hip.  A different hipcc, other flags or an innocent source edit
+Four files synchronise LDS-DMA rings with counted `s_waitcnt vmcnt(N)` and / or issue inline-asm MFMAs that hipcc pads no
+hazards for: attention_fwd.hip (r05), attention_bwd.hip, attention_bwd_fused.hip and gemm8p.hip.  A different hipcc, other flags or an innocent source edit
 can add a spill reload, a scratch access or an accumulator copy to their loops; the counted waits then cover the wrong loads and
 the results are silently wrong.  `build.py` runs these checks whenever it recompiles one of the files (a failed check fails the
 build) and tests/test_kernel_isa.py runs them on every test run.
