@@ -36,8 +36,41 @@
 namespace {
 
 #ifndef CM3P_GABL
-#define CM3P_GABL 0  // timing-only ablation builds (results wrong by construction): 1 no exponentials, 2 no max, 4 no row sums, 8 no tile DMA in the loop, 16 no barrier
+#define CM3P_GABL 0  // timing-only ablation builds (results wrong by construction): 1 no exponentials, 2 no max, 4 no row sums, 8 no tile DMA in the loop, 16 no barrier, 32 max and decision kept but no branch,
+                    // 64 no K / V fragment reloads in the loop, 128 no bf16 packs, 256 the score products start from the constant 0
 #endif
+
+// Cycle trace (trace builds only: -DCM3P_GTRACE=1, tools/attn_fwd_trace.py): every wave accumulates, in scalar registers, the shader cycles
+// (s_memtime) it spends in six regions of the sweep and writes the sums at its end - region 0: the top of a tile (counted wait, barrier,
+// validity word), 1: gaps 0-3 of a period (tail, maximum, decision), 2: gaps 4-7 (second half of PV), 3: gaps 8-11, 4: gaps 12-15 (QK^T of
+// the next sub-block), 5: prologue + epilogue.  A stamp waits for the wave's outstanding LDS reads (s_memtime returns through lgkmcnt), so the
+// build runs a few per cent slower than the product and its split, not its total, is the information.
+#ifndef CM3P_GTRACE
+#define CM3P_GTRACE 0
+#endif
+#if CM3P_GTRACE
+__device__ unsigned long long* g_fwd_trace = nullptr;
+#define GT_STAMP(k)                                            \
+    do {                                                       \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        gt_acc[k] += now__ - gt_prev;                          \
+        gt_prev = now__;                                       \
+    } while (0)
+#else
+#define GT_STAMP(k) \
+    do {            \
+    } while (0)
+#endif
+// (CM3P_GTRACE == 2: the regions are gap 0, gap 1, gap 2, gap 3 up to the branch, the branch itself, and everything else;
+//  CM3P_GTRACE == 3: no stamp inside the sweep - three per wave in all -, for the in-kernel clock: cycle total / s_memrealtime)
+#define GT1(k)                                \
+    do {                                      \
+        if constexpr (CM3P_GTRACE == 1) GT_STAMP(k); \
+    } while (0)
+#define GT2(k)                                \
+    do {                                      \
+        if constexpr (CM3P_GTRACE == 2) GT_STAMP(k); \
+    } while (0)
 
 constexpr int kGSlots = 4;
 constexpr int kGStageNoMask = 16384;          // K image (row fragments) + V image (transposed reads)
@@ -51,7 +84,8 @@ constexpr float kGDefer = 6.0f;
 // part of the loop and are copied back and forth every tile (80 v_accvgpr_* per tile in the first build of this kernel).
 // D (VGPRs) = A (AGPRs) * B (AGPRs) + C (VGPRs); D never overlaps an input
 __device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    if constexpr ((CM3P_GABL & 256) != 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
 }
 __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
@@ -91,6 +125,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     const uint16_t* kbase = qbase + nh * 64;
     const uint16_t* vbase = qbase + 2 * nh * 64;
     const int NT = (S + 63) / 64;
+#if CM3P_GTRACE
+    unsigned long long gt_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long gt_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long gt_rt0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz: with the cycle total, the clock this wave ran at)
+#endif
     // The sweep's two parts (see the loops below): [0, t_fast) tiles whose keys are all visible, t_fast a multiple of the ring; [t_fast,
     // t_end) the rest up to the tile of the last visible key.  With a key mask the workgroup scans its batch row's S bytes once.
     int first_bad = S % 64 ? S / 64 : NT, t_end = NT;
@@ -200,6 +239,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     for (int i = 0; i < 16; ++i) SB[0][i] = SB[1][i] = 0.f;  // (period 0 runs the tail of "sub-block -1": adds zeros)
 #pragma unroll
     for (int c = 0; c < 4; ++c) Pw[c] = cm3p_u32x4{0u, 0u, 0u, 0u};  // (... and its PV: adds zero)
+    if constexpr ((CM3P_GABL & 128) != 0) {  // (timing only: the packs are gone, P is a constant - NOT zero: a zero operand lowers the matrix pipe's power and raises the clock)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Pw[c][i] = 0x3e003d80u + 0x00010001u * ((lane * 37u + c * 11u + i * 5u) & 127u);
+    }
     bf16x8 Kf[2][4], Vf[4][2];
 
     auto load_k = [&](const char* st, auto blk_c, auto s_c) {
@@ -247,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         CM3P_PIN(l);
     };
     auto C2 = [&](f32x16 (&Sx)[2], int c, int h) {  // two packs: elements 4 h .. 4 h + 3 of chunk c
+        if constexpr ((CM3P_GABL & 128) != 0) return;
         const f32x16& b = Sx[c >> 1];
         const int r = 8 * (c & 1) + 4 * h;
         uint32_t w0 = pack_bf16x2(b[r], b[r + 1]), w1 = pack_bf16x2(b[r + 2], b[r + 3]);
@@ -277,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         // gap 0
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[0][0], __builtin_bit_cast(bf16x8, Pw[0]));
-        if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(0));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(0), CM3P_IC(0));
         A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3
         A(So, 3, 7, lB[UP]);
         C2(So, 3, 1);
@@ -290,10 +336,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             mb = vmax3(mb, Sc[0][8], Sc[0][9]);
             ma = vmax3(ma, Sc[0][10], Sc[0][11]);
         }
+        GT2(0);
         // gap 1
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[0][1], __builtin_bit_cast(bf16x8, Pw[0]));
-        if constexpr (RV) load_v(stV, CM3P_IC(0), CM3P_IC(1));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(0), CM3P_IC(1));
         A(So, 3, 0, lA[UP]);
         A(So, 3, 1, lB[UP]);
         if constexpr (!FAST)
@@ -304,10 +351,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             mb = vmax3(mb, Sc[1][0], Sc[1][1]);
             ma = vmax3(ma, Sc[1][2], Sc[1][3]);
         }
+        GT2(1);
         // gap 2
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
-        if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(0));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(1), CM3P_IC(0));
         if constexpr ((CM3P_GABL & 2) == 0) {
             mb = vmax3(mb, Sc[1][4], Sc[1][5]);
             ma = vmax3(ma, Sc[1][6], Sc[1][7]);
@@ -315,11 +363,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             ma = vmax3(ma, Sc[1][10], Sc[1][11]);
             mb = vmax3(mb, Sc[1][12], Sc[1][13]);
         }
+        GT2(2);
         // gap 3: the last of the maximum, the wave-uniform decision, THEN four row-sum adds, then the branch: a branch right behind the
         // compare that feeds it waits out the VALU -> scalar round trip with nothing to issue
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
-        if constexpr (RV) load_v(stV, CM3P_IC(1), CM3P_IC(1));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(1), CM3P_IC(1));
         if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(ma, Sc[1][14], Sc[1][15]);
             const float mt = vmax3(ma, mb, mb);  // this half-wave's tile maximum, relative to the reference point
@@ -331,7 +380,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             A(So, 3, 4, lA[UP]);
             A(So, 3, 5, lB[UP]);
             CM3P_SB();
-            if (__builtin_expect(any_move != 0ull, 0)) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
+            GT2(3);
+            if (((CM3P_GABL & 32) == 0) && __builtin_expect(any_move != 0ull, 0)) {  // rare after the first tiles: move the reference point (both halves of a query by the same amount)
                 // Per QUERY: only a row whose own maximum asks for it moves (both half-waves of a query see the same mf and thr).  A row's
                 // result must not depend on what the other lanes of its wave hold - the rows of a padded batch that lie past a
                 // sequence's end are other data than the clamped rows of the packed batch, and a move they trigger must not shift
@@ -371,77 +421,83 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             A(So, 3, 4, lA[UP]);
             A(So, 3, 5, lB[UP]);
         }
+        GT1(1);
+        GT2(4);
         // gaps 4-6: chunk 0
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[2][0], __builtin_bit_cast(bf16x8, Pw[2]));
-        if constexpr (RV) load_v(stV, CM3P_IC(2), CM3P_IC(0));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(2), CM3P_IC(0));
         E(Sc, 0, 0); E(Sc, 0, 1); E(Sc, 0, 2);
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[2][1], __builtin_bit_cast(bf16x8, Pw[2]));
-        if constexpr (RV) load_v(stV, CM3P_IC(2), CM3P_IC(1));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(2), CM3P_IC(1));
         E(Sc, 0, 3); E(Sc, 0, 4); E(Sc, 0, 5);
         A(Sc, 0, 0, lA[UU]); A(Sc, 0, 1, lB[UU]); A(Sc, 0, 2, lA[UU]);
         if constexpr (UU == (U == 2 ? 0 : 1)) dma_k(t + 3);
         CM3P_SB();
         mfma_o(oacc[UP][0], Vf[3][0], __builtin_bit_cast(bf16x8, Pw[3]));
-        if constexpr (RV) load_v(stV, CM3P_IC(3), CM3P_IC(0));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(3), CM3P_IC(0));
         E(Sc, 0, 6); E(Sc, 0, 7);
         A(Sc, 0, 3, lB[UU]); A(Sc, 0, 4, lA[UU]); A(Sc, 0, 5, lB[UU]);
         C2(Sc, 0, 0);
         // gaps 7-9: chunk 1 (gap 7 is the last PV MFMA: Pw[3] of the sub-block before is free from here on)
         CM3P_SB();
         mfma_o(oacc[UP][1], Vf[3][1], __builtin_bit_cast(bf16x8, Pw[3]));
-        if constexpr (RV) load_v(stV, CM3P_IC(3), CM3P_IC(1));
+        if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(3), CM3P_IC(1));
         E(Sc, 1, 0); E(Sc, 1, 1); E(Sc, 1, 2);
         A(Sc, 0, 6, lA[UU]); A(Sc, 0, 7, lB[UU]);
         C2(Sc, 0, 1);
+        GT1(2);
         CM3P_SB();
         mfma_s0(So[0], Kf[0][0], qf[UN][0], negref[UN]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(0), CM3P_IC(0));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(0), CM3P_IC(0));
         E(Sc, 1, 3); E(Sc, 1, 4); E(Sc, 1, 5);
         A(Sc, 1, 0, lA[UU]); A(Sc, 1, 1, lB[UU]); A(Sc, 1, 2, lA[UU]);
         CM3P_SB();
         mfma_s(So[0], Kf[0][1], qf[UN][1]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(0), CM3P_IC(1));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(0), CM3P_IC(1));
         E(Sc, 1, 6); E(Sc, 1, 7);
         A(Sc, 1, 3, lB[UU]); A(Sc, 1, 4, lA[UU]); A(Sc, 1, 5, lB[UU]);
         C2(Sc, 1, 0);
         // gaps 10-12: chunk 2
         CM3P_SB();
         mfma_s(So[0], Kf[0][2], qf[UN][2]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(0), CM3P_IC(2));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(0), CM3P_IC(2));
         E(Sc, 2, 0); E(Sc, 2, 1); E(Sc, 2, 2);
         A(Sc, 1, 6, lA[UU]); A(Sc, 1, 7, lB[UU]);
         C2(Sc, 1, 1);
         CM3P_SB();
         mfma_s(So[0], Kf[0][3], qf[UN][3]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(0), CM3P_IC(3));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(0), CM3P_IC(3));
         E(Sc, 2, 3); E(Sc, 2, 4); E(Sc, 2, 5);
         A(Sc, 2, 0, lA[UU]); A(Sc, 2, 1, lB[UU]); A(Sc, 2, 2, lA[UU]);
         if constexpr (UU == U - 1) dma_v(t + 3);
+        GT1(3);
         CM3P_SB();
         mfma_s0(So[1], Kf[1][0], qf[UN][0], negref[UN]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(0));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(1), CM3P_IC(0));
         E(Sc, 2, 6); E(Sc, 2, 7);
         A(Sc, 2, 3, lB[UU]); A(Sc, 2, 4, lA[UU]); A(Sc, 2, 5, lB[UU]);
         C2(Sc, 2, 0);
         // gaps 13-15: chunk 3 (its last two adds and packs run in gap 0 of the next period)
         CM3P_SB();
         mfma_s(So[1], Kf[1][1], qf[UN][1]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(1));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(1), CM3P_IC(1));
         E(Sc, 3, 0); E(Sc, 3, 1); E(Sc, 3, 2);
         A(Sc, 2, 6, lA[UU]); A(Sc, 2, 7, lB[UU]);
         C2(Sc, 2, 1);
         CM3P_SB();
         mfma_s(So[1], Kf[1][2], qf[UN][2]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(2));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(1), CM3P_IC(2));
         E(Sc, 3, 3); E(Sc, 3, 4); E(Sc, 3, 5);
         CM3P_SB();
         mfma_s(So[1], Kf[1][3], qf[UN][3]);
-        if constexpr (RK) load_k(stKn, CM3P_IC(1), CM3P_IC(3));
+        if constexpr (RK && (CM3P_GABL & 64) == 0) load_k(stKn, CM3P_IC(1), CM3P_IC(3));
         E(Sc, 3, 6); E(Sc, 3, 7);
         C2(Sc, 3, 0);
         CM3P_SB();
+        GT1(4);
+        GT2(5);
     };
 
     // ---- the key sweep, four tiles (= the ring) per trip so that a tile's slot is a compile-time constant ---------------------------
@@ -467,6 +523,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
             const unsigned long long vsh = valid >> (4 * hh);
             w0 = (uint32_t)vsh, w1 = (uint32_t)(vsh >> 32);
         }
+        GT1(0);
+        GT2(5);
         if constexpr (U == 4) {
             period(CM3P_IC(0), slot_c, fast_c, SA, SB, tile_bad, w0, w1, t);
             period(CM3P_IC(1), slot_c, fast_c, SB, SA, tile_bad, w0, w1, t);
@@ -482,6 +540,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     // C4), the rest - from the ring-aligned tile of the first invisible key to the tile of the last visible one - the stream with one
     // branch per block.  Tiles behind the last visible key are not visited at all: every score of theirs would be -inf, p = 0.
     // (Both copies inside ONE loop behind an if / else per tile made hipcc spill 1500 registers: the copies must not meet in a phi.)
+    GT_STAMP(5);
     int t = 0;
     for (; t < t_fast; t += 4) {
         tile(CM3P_IC(0), CM3P_IC(1), t);
@@ -526,6 +585,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         if (qrow < S && hh == 0)
             lse[sv.stat0 + qrow] = l_tot > 0.f ? (ref[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
     }
+#if CM3P_GTRACE
+    GT_STAMP(5);
+    if (g_fwd_trace && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_fwd_trace[((size_t)blockIdx.x * 4 + wid) * 8 + k] = gt_acc[k];
+        g_fwd_trace[((size_t)blockIdx.x * 4 + wid) * 8 + 6] = (unsigned long long)((t_end + 3) & ~3);
+        g_fwd_trace[((size_t)blockIdx.x * 4 + wid) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - gt_rt0;
+    }
+#endif
 }
 
 }  // namespace
@@ -553,7 +621,13 @@ int cm3p_launch_attn_fwd_global(const void* qkv, void* out, float* lse, const ui
     return CM3P_OK;
 }
 
-int cm3p_ablation_flags_attention_fwd() { return (CM3P_GABL); }
+int cm3p_ablation_flags_attention_fwd() { return (CM3P_GABL) | ((CM3P_GTRACE) << 8); }
+#if CM3P_GTRACE
+extern "C" int cm3p_debug_set_fwd_trace(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 #if CM3P_DMA_AUDIT
 int cm3p_audit_set_attention_fwd(void* buf) { return cm3p_audit_set_local(buf); }
 #endif

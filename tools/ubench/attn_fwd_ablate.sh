@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing-only ablation builds of the pipelined global attention forward (csrc/attention_fwd.hip, -DCM3P_GABL=mask: 1 no exponentials,
-# 2 no max / reference decision, 4 no row sums, 8 no tile DMA in the loop, 16 no barrier; results are wrong by construction) and
+# 2 no max / reference decision, 4 no row sums, 8 no tile DMA in the loop, 16 no barrier, 32 no reference-move branch, 64 no K / V fragment reloads,
+# 128 no bf16 packs, 256 score products start from the constant 0; results are wrong by construction) and
 # variant builds (-DCM3P_FWD_U=2: 64 queries per wave), each timed by tools/attn_fwd_ab.py through CM3P_HIP_LIB.  Run from the repo
 # root on the GPU box:   bash tools/ubench/attn_fwd_ablate.sh "0 1 2 4 8 16 7 31" ["-DCM3P_FWD_U=2" ...]
 R=$(pwd)
