@@ -446,7 +446,9 @@ def _attn_case(K, B, S, nh, window, lens, seed, check_bwd=True, prescaled=False)
         qkv = qkv_dev.clone()
         qkv[:, :, 0] = (qkv_dev[:, :, 0].float() / c)  # the reference's q (fp32, not representable in bf16: kept as float below)
     mask = None
-    if lens is not None:
+    if torch.is_tensor(lens):
+        mask = lens.long()  # (an arbitrary (B, S) key mask)
+    elif lens is not None:
         mask = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).long()
     allowed = O.attention_allowed(mask, B, S, window if window >= 0 else None)
     if allowed is None and window >= 0:
@@ -507,6 +509,29 @@ def test_attention_random_shapes(K, seed):
     if seed % 3 != 0:
         lens = [S] + [int(torch.randint(1, S + 1, (1,), generator=g)) for _ in range(B - 1)]
     _attn_case(K, B, S, nh, window, lens, 2000 + seed, prescaled=seed % 4 < 2)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_attention_global_arbitrary_key_masks(K, seed):
+    """The key mask of the reference is any (B, S) 0 / 1 tensor (TF:masking_utils.py:168-179 - right padding is only the usual case).
+    Seeded sweep over masks with holes, left padding, a row with one visible key, a row with none, and lengths on both sides of the
+    pipelined forward's ring (4 tiles of 64 keys) and its two loops (tiles in front of the first invisible key run without masking
+    code, tiles behind the last visible one are not visited): forward and backward against the fp32 restatement, dead rows exact."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    S = [255, 256, 257, 300, 511, 640, 769, 1024, 1100, 1409][seed]
+    B, nh = 4, 1 + seed % 3
+    m = torch.ones(B, S, dtype=torch.long)
+    m[0] = (torch.rand(S, generator=g) < 0.7).long()                         # holes everywhere
+    cut = int(torch.randint(1, S, (1,), generator=g))
+    m[1, :cut] = 0                                                           # left padding
+    if seed % 2:
+        m[1, cut + (S - cut) // 2:] = 0                                      # ... and right padding behind it
+    m[2] = 0
+    if seed % 3:
+        m[2, int(torch.randint(0, S, (1,), generator=g))] = 1                # one visible key (seed % 3 == 0: none at all)
+    first = int(torch.randint(S // 2, S, (1,), generator=g))
+    m[3, first] = 0                                                          # all visible but one key late in the sweep
+    _attn_case(K, B, S, nh, -1, m, 7100 + seed, prescaled=seed % 4 != 3)
 
 
 def test_attention_fused_backward_matches_pair_and_is_deterministic(K, monkeypatch):
