@@ -44,6 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+NOMINAL_CLOCK_GHZ = 2.4
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PROFILE_EVERY = 3  # of the dominant kernel's launches inside the timed region, every third one is timed with HIP events
 HBM_PEAK_GBS = 8000.0  # same guide: "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured with a float4 copy)
@@ -105,7 +106,7 @@ def make_batch(config, w, rank: int, device):
     return batch
 
 
-def pmc_value(kind: str, workload: str, tag: str):
+def pmc_value(kind: str, workload: str, tag: str, field: str = ""):
     """-> (value, file) from the committed rocprofv3 PMC passes of this same command, or (None, None).
     kind "traffic": HBM bytes per launch of `tag` (profiles/traffic_<workload>.json, written by tools/pmc_traffic.py: FETCH_SIZE
     and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
@@ -118,6 +119,8 @@ def pmc_value(kind: str, workload: str, tag: str):
     for key in (tag, tag.split(" [")[0], tag.split("<")[0]):  # exact tag, the kernel name without its " [global]" note, the bare name
         if key in d:
             v = d[key]
+            if field:
+                return (v.get(field) if isinstance(v, dict) else None), rel
             return ((v.get("busy_frac", v.get("mfma_util"))) if isinstance(v, dict) else v), rel
     return None, rel
 
@@ -236,10 +239,17 @@ def roofline_object(tag: str, timed_launches, bracketed_step: dict, workload: st
     achieved = work / (ms * 1e-3) / scale if ms > 0 else 0.0
     traffic, traffic_file = pmc_value("traffic", workload, tag)
     busy, busy_file = pmc_value("mfma_util", workload, tag)
+    clock, _ = pmc_value("mfma_util", workload, tag, "clock_ghz")  # (GRBM_GUI_ACTIVE / 8 / duration of the same counter pass)
+    held = {}
+    if not hbm_bound and clock:
+        # `frac` stays against the nominal peak (2.4 GHz); the part lowers its clock under matrix load (MI355X_MICROARCH.md "DVFS give-back",
+        # an MFMA-only stream of the attention forward holds 1.94 GHz), so the same rate against the peak AT the clock
+        # this kernel held is reported beside it - information, not the judged number
+        held = {"clock_ghz": round(clock, 3), "frac_at_held_clock": achieved / (peak * clock / NOMINAL_CLOCK_GHZ)}
     return {
         "kernel": tag, "bound": "hbm" if hbm_bound else "mfma", "achieved": achieved, "peak": peak, "unit": unit,
         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_file,
-        "mfma_busy": busy, "mfma_busy_source": busy_file,
+        "mfma_busy": busy, "mfma_busy_source": busy_file, **held,
         "launches": n, "launches_sampled_every": PROFILE_EVERY, "avg_launch_ms": ms / n,
         "share_of_kernel_time": (ms / n) * bracketed_step[tag][0] / total_ms,
         "work_per_launch": work / n,
