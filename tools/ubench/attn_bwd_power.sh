@@ -1,6 +1,7 @@
 #!/bin/bash
 # The fused global attention backward's ablation ladder with counters (the forward's is attn_fwd_power.sh): per timing-only build
-# (-DCM3P_FABL=mask: 1 no barrier, 2 no tile DMA in the loop, 4 no dS image writes, 8 no dQ operand reads, 16 no slab stores, 32 no dQ MFMAs;
+# (-DCM3P_FABL=mask: 1 no barrier, 2 no tile DMA in the loop, 4 no dS image writes, 8 no dQ operand reads, 16 no slab stores, 32 no dQ MFMAs,
+# 64 no exponentials, 128 no dS multiplies, 256 no bf16 packs, 512 no Q / dO row-fragment reloads, 1024 no transposed fragment reloads;
 # results wrong by construction) one un-profiled timing leg and ONE counter pass at the C4 shape: matrix-busy share, cycles, and the clock the
 # launch held (GRBM_GUI_ACTIVE / 8 / duration of the counter pass).
 #   bash tools/ubench/attn_bwd_power.sh "0 4 8 12 28 60 62"

@@ -1,3 +1,9 @@
+// VARIANT, NOT PART OF THE LIBRARY (r05 measurement; tools/ubench/variants/README): csrc/attention_bwd_fused.hip with the step's vector
+// work - exponentials, packs, dS multiplies - re-placed in slices of 16 issue cycles, one per MFMA gap, the next block's fragment reloads at
+// most two 16-byte reads per gap, and every op held in its slice (HOLD / input pins).  Bit-identical results (tools/attn_bwd_digest.py),
+// no scratch, tools/isa_gapcost.py: 44.3 -> 36.2 cycles per MFMA "as placed" - and the same time and the same cycle count on the GPU
+// (DESIGN.md section 4 r05).  Build: copy over csrc/attention_bwd_fused.hip, or compile this file in its place (it includes ../../.. paths
+// relative to csrc: cp it to csrc/ under another name first).
 // Backward of the GLOBAL attention layers as ONE key-parallel kernel that executes each of the five matrix products once
 // (S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS, dQ^T += K^T dS^T), head_dim 64, gfx950.
 // cm3p_attn_bwd_fused: the same mathematics as cm3p_attn_bwd with window < 0 (attention_bwd.hip, which recomputes S and dP in
@@ -49,17 +55,8 @@ namespace {
 #ifndef CM3P_FABL
 #define CM3P_FABL 0  // timing-only ablation builds (tools/ubench/attn_bwd_ablate.sh; results are wrong by construction): 1 no barrier,
 #endif               // 2 no tile DMA in the loop, 4 no dS image writes, 8 no dQ operand reads, 16 no slab stores, 32 no dQ MFMAs,
-                     // 64 no exponentials, 128 no dS multiplies, 256 no bf16 packs (P / dS fragments a non-zero constant), 512 no Q / dO
-                     // row-fragment and statistics reloads, 1024 no transposed Q^T / dO^T fragment reloads
-
-// Wait trace (-DCM3P_FTRACE=1, tools/attn_bwd_trace.py): per wave the cycles spent (0) at the counted vmcnt wait - the DMA of tile t+1 not landed -,
-// (1) at the LDS drain + the tile's one barrier, and (2) in all; the stamps are read behind the barrier's own lgkmcnt(0), so they add no wait.
-#ifndef CM3P_FTRACE
-#define CM3P_FTRACE 0
-#endif
-#if CM3P_FTRACE
-__device__ unsigned long long* g_bwdf_trace = nullptr;
-#endif
+                     // 64 no exponentials, 128 no dS multiplies, 256 no bf16 packs (P / dS fragments constant), 512 no Q / dO row-fragment
+                     // and statistics reloads, 1024 no transposed Q^T / dO^T fragment reloads
 
 constexpr int kFStage = 16384 + 512;        // slot: 4 groups of [16 Q rows | 16 dO rows] (128-byte rows) + [2][64] floats
 constexpr int kFSlots = 3;
@@ -94,13 +91,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// p = min(2^x, 1) (v_exp_f32 with the clamp bit; NaN -> 0)
-template <bool PRE>
-__device__ __forceinline__ void exp2c_pair(f32x16& s, int i, float cm) {
-    if constexpr ((CM3P_FABL & 64) != 0) return;
-    s[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(PRE ? s[i] : s[i] * cm), 0.f, 1.f);
-    s[i + 1] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(PRE ? s[i + 1] : s[i + 1] * cm), 0.f, 1.f);
-}
+// (p = min(2^x, 1): v_exp_f32 with the clamp bit; NaN -> 0 - see E1 in step())
 
 // ---- prep -----------------------------------------------------------------------------------------------------------------------
 // grid (tiles + kFPadTiles, nh, B), 256 threads: four threads per row of the tile
@@ -402,14 +393,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     // block X (key block KBX), whose dS also goes to image WBUF (query-column chunks WCB ..), and four k-steps KS0 .. KS0+3 of the
     // dQ product of the epoch in image RBUF (FIRST: the epoch's first k-step starts from zero).  Fragment reloads as in
     // attn_bwd_dkv3_kernel; `hook(c)` is called once per chunk (0..15: behind the chunk's MFMA; 16..19: behind the dQ MFMAs).
-    auto to_frag = [&](const f32x16& a, int sp) -> bf16x8 {
-        if constexpr ((CM3P_FABL & 256) != 0) {  // (timing only: a non-zero constant - zero operands lower the matrix pipe's power)
-            (void)a;
-            return __builtin_bit_cast(bf16x8, cm3p_u32x4{0x3e003d80u + 0x00010001u * (lane & 63), 0x3d903e10u, 0x3e203da0u + (unsigned)sp, 0x3db03e30u});
-        } else {
-            return acc_to_frag(a, sp);
-        }
-    };
     auto step = [&](auto kbx_c, auto kby_c, auto wbuf_c, auto wcb_c, auto rbuf_c, auto ks0_c, auto first_c, auto nrbuf_c, auto nks0_c, f32x16& Xs, f32x16& Xdp,
                     f32x16& Ys, f32x16& Ydp, const char* nS, const char* nSi, const char* nG, auto&& hook) {
         constexpr int KBX = decltype(kbx_c)::value, KBY = decltype(kby_c)::value, WBUF = decltype(wbuf_c)::value;
@@ -418,131 +401,249 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         constexpr int NRBUF = decltype(nrbuf_c)::value, NKS0 = decltype(nks0_c)::value;  // the next step's first k-step (-1: none yet)
         char* const dsw = smem + 32768 * WBUF + 4096 * KBX;
 #define CM3P_HOOK(C) hook(std::integral_constant<int, (C)>{})
+        // The step's vector work - for block X 16 exponentials, 8 packs of P, 16 dS multiplies, 8 packs of dS - in slices of 16 issue
+        // cycles, one per MFMA gap G = 0 .. 19 (issue order: c0 c1 c2 c3 q16 c4 .. c7 q17 c8 .. c11 q18 c12 .. c15 q19).  Prices
+        // (tools/ubench/mfma_cvt_dep.hip, mfma_vgpr_dst.hip): v_exp 8, v_cvt_pk_bf16_f32 8 - not the 4-5 of a lone pack -, v_mul 4; beside an
+        // MFMA (8 of its 32 cycles) 24 cycles of vector issue hide, and a gap that overruns is never bought back by a light one
+        // (tools/isa_gapcost.py).  The first placement put 4 packs + 4 multiplies (48 cycles) into the gaps of the gradient MFMAs and
+        // nothing beside the dQ MFMAs.  Deadlines: P k-step 0 (pfw[0..3]) before the MFMA of gap 10, dS k-step 0 before 12, P k-step 1
+        // before 15, dS k-step 1 before 17 - each is finished at least one gap earlier, so no pack sits right in front of its reader.  The
+        // last four gaps run the first eight exponentials of block Y (whose scores are complete since gap 7), i.e. of the NEXT step's X.
+        cm3p_u32x4 pf0w, pf1w, ds0w, ds1w;
+        if constexpr ((CM3P_FABL & 256) != 0) {  // (timing only: non-zero constants - zero operands lower the matrix pipe's power)
+            pf0w = pf1w = ds0w = ds1w = cm3p_u32x4{0x3e003d80u + 0x00010001u * (lane & 63), 0x3d903e10u, 0x3e203da0u, 0x3db03e30u};
+        }
+        auto E1 = [&](f32x16& sx, int i) {
+            if constexpr ((CM3P_FABL & 64) != 0) return;
+            const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(PRE ? sx[i] : sx[i] * cm), 0.f, 1.f);
+            asm volatile("" ::"v"(e));  // (pins the instruction in its slice: pure vector work is otherwise placed by the DAG scheduler,
+            sx[i] = e;                  //  which a sched_barrier does not bind - input only: an asm OUTPUT would cost a wait state)
+        };
+        auto CP = [&](int j) {  // P: registers 2 j, 2 j + 1 -> dword j & 3 of k-step j >> 2
+            if constexpr ((CM3P_FABL & 256) != 0) return;
+            const uint32_t w = pack_bf16x2(Xs[2 * j], Xs[2 * j + 1]);
+            asm volatile("" ::"v"(w));
+            if (j < 4) pf0w[j & 3] = w;
+            else pf1w[j & 3] = w;
+        };
+        auto M1 = [&](int i) {
+            if constexpr ((CM3P_FABL & 128) != 0) return;
+            const float d = Xdp[i] * Xs[i];
+            asm volatile("" ::"v"(d));
+            Xdp[i] = d;
+        };
+        auto CD = [&](int j) {
+            if constexpr ((CM3P_FABL & 256) != 0) return;
+            const uint32_t w = pack_bf16x2(Xdp[2 * j], Xdp[2 * j + 1]);
+            asm volatile("" ::"v"(w));
+            if (j < 4) ds0w[j & 3] = w;
+            else ds1w[j & 3] = w;
+        };
+        // Pure vector work has no place of its own in the DAG scheduler's eyes: the input-only pin behind each result keeps it from sinking
+        // below its slice, and HOLD - an empty asm that "rewrites" the slice's first inputs, issued in front of the chunk's MFMA so that no
+        // reader follows it directly (an asm output right in front of its reader costs wait states) - keeps it from rising above it.
+#define CM3P_H(V, I)                  \
+    do {                              \
+        float t__ = V[I];             \
+        asm volatile("" : "+v"(t__)); \
+        V[I] = t__;                   \
+    } while (0)
+        auto HOLD = [&](auto g_c) {
+            constexpr int G = decltype(g_c)::value;
+            if constexpr (G == 0) { CM3P_H(Xs, 0); CM3P_H(Xs, 2); }
+            if constexpr (G == 1) { CM3P_H(Xs, 4); CM3P_H(Xs, 6); }
+            if constexpr (G == 2) { CM3P_H(Xdp, 0); CM3P_H(Xdp, 1); CM3P_H(Xdp, 2); CM3P_H(Xdp, 3); }
+            if constexpr (G == 3) { CM3P_H(Xdp, 4); CM3P_H(Xdp, 5); CM3P_H(Xdp, 6); CM3P_H(Xdp, 7); }
+            if constexpr (G == 4) { CM3P_H(Xdp, 0); CM3P_H(Xdp, 2); }
+            if constexpr (G == 5) { CM3P_H(Xdp, 4); CM3P_H(Xdp, 6); }
+            if constexpr (G == 6) { CM3P_H(Xs, 8); CM3P_H(Xs, 9); }
+            if constexpr (G == 7) { CM3P_H(Xs, 10); CM3P_H(Xs, 11); }
+            if constexpr (G == 8) { CM3P_H(Xs, 8); CM3P_H(Xs, 10); }
+            if constexpr (G == 9) { CM3P_H(Xs, 12); CM3P_H(Xs, 13); }
+            if constexpr (G == 10) { CM3P_H(Xs, 14); CM3P_H(Xs, 15); }
+            if constexpr (G == 11) { CM3P_H(Xs, 12); CM3P_H(Xs, 14); }
+            if constexpr (G == 12) { CM3P_H(Xdp, 8); CM3P_H(Xdp, 9); CM3P_H(Xdp, 10); CM3P_H(Xdp, 11); }
+            if constexpr (G == 13) { CM3P_H(Xdp, 12); CM3P_H(Xdp, 13); CM3P_H(Xdp, 14); CM3P_H(Xdp, 15); }
+            if constexpr (G == 14) { CM3P_H(Xdp, 8); CM3P_H(Xdp, 10); }
+            if constexpr (G == 15) { CM3P_H(Xdp, 12); CM3P_H(Xdp, 14); }
+            if constexpr (G == 16) { CM3P_H(Ys, 0); CM3P_H(Ys, 1); }
+            if constexpr (G == 17) { CM3P_H(Ys, 2); CM3P_H(Ys, 3); }
+            if constexpr (G == 18) { CM3P_H(Ys, 4); CM3P_H(Ys, 5); }
+            if constexpr (G == 19) { CM3P_H(Ys, 6); CM3P_H(Ys, 7); }
+        };
+        auto VS = [&](auto g_c) {
+            constexpr int G = decltype(g_c)::value;
+            if constexpr (G == 0) { CP(0); CP(1); }
+            if constexpr (G == 1) { CP(2); CP(3); }
+            if constexpr (G == 2) { M1(0); M1(1); M1(2); M1(3); }
+            if constexpr (G == 3) { M1(4); M1(5); M1(6); M1(7); }
+            if constexpr (G == 4) { CD(0); CD(1); }
+            if constexpr (G == 5) { CD(2); CD(3); }
+            if constexpr (G == 6) { E1(Xs, 8); E1(Xs, 9); }
+            if constexpr (G == 7) { E1(Xs, 10); E1(Xs, 11); }
+            if constexpr (G == 8) { CP(4); CP(5); }
+            if constexpr (G == 9) { E1(Xs, 12); E1(Xs, 13); }
+            if constexpr (G == 10) { E1(Xs, 14); E1(Xs, 15); }
+            if constexpr (G == 11) { CP(6); CP(7); }
+            if constexpr (G == 12) { M1(8); M1(9); M1(10); M1(11); }
+            if constexpr (G == 13) { M1(12); M1(13); M1(14); M1(15); }
+            if constexpr (G == 14) { CD(4); CD(5); }
+            if constexpr (G == 15) { CD(6); CD(7); }
+            if constexpr (G == 16) { E1(Ys, 0); E1(Ys, 1); }
+            if constexpr (G == 17) { E1(Ys, 2); E1(Ys, 3); }
+            if constexpr (G == 18) { E1(Ys, 4); E1(Ys, 5); }
+            if constexpr (G == 19) { E1(Ys, 6); E1(Ys, 7); }
+        };
+#define CM3P_VS(G) VS(std::integral_constant<int, (G)>{})
+#define CM3P_HOLD(G) HOLD(std::integral_constant<int, (G)>{})
         CM3P_SB();
+        CM3P_HOLD(0);
         mfma_vc(Ys, Qf[0], kf[KBY][0], isv);
-        exp2c_pair<PRE>(Xs, 0, cm);
+        CM3P_VS(0);
         if constexpr (FIRST) load_dq_operand(dqB0, RBUF, KS0);  // (the epoch was published a moment ago)
         load_dq_operand(dqB1, RBUF, KS0 + 1);
         CM3P_HOOK(0);
         CM3P_SB();
+        CM3P_HOLD(1);
         mfma_vc(Ydp, Gf[0], vf[KBY][0], idv);
-        exp2c_pair<PRE>(Xs, 2, cm);
+        CM3P_VS(1);
+        // (the next 32-query block's fragments, each behind the last MFMA that reads the one it replaces and at most two 16-byte reads per
+        //  gap: four waves x 3 KB in one gap are more than the LDS array delivers in 32 cycles - 256 B per clock -, and the gap stretches to 48)
         if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
             Qf[0] = ld_frag(nS + oR[0]);
             Gf[0] = ld_frag(nS + 2048 + oR[0]);
-            load_init(nSi, isv, 0, 0);
         }
         CM3P_HOOK(1);
         CM3P_SB();
+        CM3P_HOLD(2);
         mfma_va(Ys, Qf[1], kf[KBY][1]);
-        exp2c_pair<PRE>(Xs, 4, cm);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
-            load_init(nSi, isv, 0, 1);
-            Qf[1] = ld_frag(nS + oR[1]);
-        }
+        CM3P_VS(2);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) load_init(nSi, isv, 0, 0);
         CM3P_HOOK(2);
         CM3P_SB();
+        CM3P_HOLD(3);
         mfma_va(Ydp, Gf[1], vf[KBY][1]);
-        exp2c_pair<PRE>(Xs, 6, cm);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
-            Gf[1] = ld_frag(nS + 2048 + oR[1]);
-            load_init(nSi, idv, 1, 0);
-        }
+        CM3P_VS(3);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) load_init(nSi, isv, 0, 1);
         CM3P_HOOK(3);
         CM3P_SB();
+        CM3P_HOLD(4);
         dq_mfma(std::integral_constant<int, KS0>{}, first_c, dqB0);
+        CM3P_VS(4);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
+            Qf[1] = ld_frag(nS + oR[1]);
+            Gf[1] = ld_frag(nS + 2048 + oR[1]);
+        }
         CM3P_HOOK(16);
         CM3P_SB();
+        CM3P_HOLD(5);
         mfma_va(Ys, Qf[2], kf[KBY][2]);
-        exp2c_pair<PRE>(Xs, 8, cm);
+        CM3P_VS(5);
         load_dq_operand(dqB0, RBUF, KS0 + 2);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
-            Qf[2] = ld_frag(nS + oR[2]);
-            load_init(nSi, idv, 1, 1);
-        }
         CM3P_HOOK(4);
         CM3P_SB();
+        CM3P_HOLD(6);
         mfma_va(Ydp, Gf[2], vf[KBY][2]);
-        exp2c_pair<PRE>(Xs, 10, cm);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) Gf[2] = ld_frag(nS + 2048 + oR[2]);
+        CM3P_VS(6);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) load_init(nSi, idv, 1, 0);
         CM3P_HOOK(5);
         CM3P_SB();
+        CM3P_HOLD(7);
         mfma_va(Ys, Qf[3], kf[KBY][3]);
-        exp2c_pair<PRE>(Xs, 12, cm);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) Qf[3] = ld_frag(nS + oR[3]);
+        CM3P_VS(7);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) load_init(nSi, idv, 1, 1);
         CM3P_HOOK(6);
         CM3P_SB();
+        CM3P_HOLD(8);
         mfma_va(Ydp, Gf[3], vf[KBY][3]);
-        exp2c_pair<PRE>(Xs, 14, cm);
-        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) Gf[3] = ld_frag(nS + 2048 + oR[3]);
+        CM3P_VS(8);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
+            Qf[2] = ld_frag(nS + oR[2]);
+            Gf[2] = ld_frag(nS + 2048 + oR[2]);
+        }
         CM3P_HOOK(7);
         CM3P_SB();
+        CM3P_HOLD(9);
         dq_mfma(std::integral_constant<int, KS0 + 1>{}, std::integral_constant<int, 0>{}, dqB1);
+        CM3P_VS(9);
+        if constexpr (KBY == 1 && (CM3P_FABL & 512) == 0) {
+            Qf[3] = ld_frag(nS + oR[3]);
+            Gf[3] = ld_frag(nS + 2048 + oR[3]);
+        }
         CM3P_HOOK(17);
         CM3P_SB();
+        CM3P_HOLD(10);
         // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS; dS -> image
-        const bf16x8 pf0 = to_frag(Xs, 0);
-        dv[0][KBX] = mfma32(gT[0][0], pf0, dv[0][KBX]);
+        dv[0][KBX] = mfma32(gT[0][0], __builtin_bit_cast(bf16x8, pf0w), dv[0][KBX]);
+        CM3P_VS(10);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < ((CM3P_FABL & 128) ? 0 : 4); ++i) Xdp[i] *= Xs[i];
         load_dq_operand(dqB1, RBUF, KS0 + 3);
         CM3P_HOOK(8);
         CM3P_SB();
-        dv[1][KBX] = mfma32(gT[0][1], pf0, dv[1][KBX]);
+        CM3P_HOLD(11);
+        dv[1][KBX] = mfma32(gT[0][1], __builtin_bit_cast(bf16x8, pf0w), dv[1][KBX]);
+        CM3P_VS(11);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 1, 0);
-#pragma unroll
-        for (int i = 4; i < ((CM3P_FABL & 128) ? 0 : 8); ++i) Xdp[i] *= Xs[i];
-        const bf16x8 ds0 = to_frag(Xdp, 0);
         CM3P_HOOK(9);
         CM3P_SB();
-        dk[0][KBX] = mfma32(qT[0][0], ds0, dk[0][KBX]);
+        CM3P_HOLD(12);
+        dk[0][KBX] = mfma32(qT[0][0], __builtin_bit_cast(bf16x8, ds0w), dk[0][KBX]);
+        CM3P_VS(12);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 0, 1);
-        const bf16x8 pf1 = to_frag(Xs, 1);
         if constexpr ((CM3P_FABL & 4) == 0) {
-            const uint4 w = __builtin_bit_cast(uint4, ds0);
-            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 0]) = uint2{w.x, w.y};
-            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 1]) = uint2{w.z, w.w};
+            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 0]) = uint2{ds0w[0], ds0w[1]};
+            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 1]) = uint2{ds0w[2], ds0w[3]};
         }
         CM3P_HOOK(10);
         CM3P_SB();
-        dk[1][KBX] = mfma32(qT[0][1], ds0, dk[1][KBX]);
+        CM3P_HOLD(13);
+        dk[1][KBX] = mfma32(qT[0][1], __builtin_bit_cast(bf16x8, ds0w), dk[1][KBX]);
+        CM3P_VS(13);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 1, 1);
-#pragma unroll
-        for (int i = 8; i < ((CM3P_FABL & 128) ? 0 : 12); ++i) Xdp[i] *= Xs[i];
         CM3P_HOOK(11);
         CM3P_SB();
+        CM3P_HOLD(14);
         dq_mfma(std::integral_constant<int, KS0 + 2>{}, std::integral_constant<int, 0>{}, dqB0);
+        CM3P_VS(14);
         CM3P_HOOK(18);
         CM3P_SB();
-        dv[0][KBX] = mfma32(gT[1][0], pf1, dv[0][KBX]);
+        CM3P_HOLD(15);
+        dv[0][KBX] = mfma32(gT[1][0], __builtin_bit_cast(bf16x8, pf1w), dv[0][KBX]);
+        CM3P_VS(15);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 0, 0);
-#pragma unroll
-        for (int i = 12; i < ((CM3P_FABL & 128) ? 0 : 16); ++i) Xdp[i] *= Xs[i];
-        const bf16x8 ds1 = to_frag(Xdp, 1);
         if constexpr (NKS0 >= 0) load_dq_operand(dqB0, NRBUF, NKS0);
         CM3P_HOOK(12);
         CM3P_SB();
-        dv[1][KBX] = mfma32(gT[1][1], pf1, dv[1][KBX]);
+        CM3P_HOLD(16);
+        dv[1][KBX] = mfma32(gT[1][1], __builtin_bit_cast(bf16x8, pf1w), dv[1][KBX]);
+        CM3P_VS(16);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 1, 0);
         if constexpr ((CM3P_FABL & 4) == 0) {
-            const uint4 w = __builtin_bit_cast(uint4, ds1);
-            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 2]) = uint2{w.x, w.y};
-            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 3]) = uint2{w.z, w.w};
+            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 2]) = uint2{ds1w[0], ds1w[1]};
+            *reinterpret_cast<uint2*>(dsw + dsW[WCB + 3]) = uint2{ds1w[2], ds1w[3]};
         }
         CM3P_HOOK(13);
         CM3P_SB();
-        dk[0][KBX] = mfma32(qT[1][0], ds1, dk[0][KBX]);
+        CM3P_HOLD(17);
+        dk[0][KBX] = mfma32(qT[1][0], __builtin_bit_cast(bf16x8, ds1w), dk[0][KBX]);
+        CM3P_VS(17);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 0, 1);
         CM3P_HOOK(14);
         CM3P_SB();
-        dk[1][KBX] = mfma32(qT[1][1], ds1, dk[1][KBX]);
+        CM3P_HOLD(18);
+        dk[1][KBX] = mfma32(qT[1][1], __builtin_bit_cast(bf16x8, ds1w), dk[1][KBX]);
+        CM3P_VS(18);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 1, 1);
         CM3P_HOOK(15);
         CM3P_SB();
+        CM3P_HOLD(19);
         dq_mfma(std::integral_constant<int, KS0 + 3>{}, std::integral_constant<int, 0>{}, dqB1);
+        CM3P_VS(19);
         CM3P_HOOK(19);
         CM3P_SB();
+#undef CM3P_VS
+#undef CM3P_HOLD
+#undef CM3P_H
 #undef CM3P_HOOK
     };
 
@@ -571,9 +672,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     // image DP while the dQ product walks epoch t-1 in image DP ^ 1; the barrier publishes epoch t and tile t+1 (whose DMA each
     // wave has waited for) and retires epoch t-1 and slot SL; steps 2 / 3 start epoch t+1 in image DP ^ 1 and the dQ product of
     // epoch t, store epoch t-1's block and issue the DMA of tile t+3 into slot SL.
-#if CM3P_FTRACE
-    unsigned long long ft_acc[2] = {0, 0};
-#endif
     auto tile = [&](auto slot_c, auto par_c, int t) {
         constexpr int SL = decltype(slot_c)::value, NS = (SL + 1) % kFSlots, DP = decltype(par_c)::value;
         using WA = std::integral_constant<int, DP>;
@@ -584,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         auto no_hook = [&](auto) {};
         auto pre_hook = [&](auto c) {
             constexpr int C = decltype(c)::value;
-            if constexpr (C == 16) dma_addr(t + 3);
+            if constexpr (C == 17) dma_addr(t + 3);  // (as late as the allocator lets it: the five offsets stay live up to the DMA of step 2, and every VGPR is in use)
         };
         // Behind the barrier: the DMA of tile t+3 first (slot SL was retired a moment ago), then epoch t-1's finished dQ^T block:
         // accumulators -> bf16 -> the wave's transposition buffer -> two 16-byte pieces of whole rows per lane -> two coalesced
@@ -645,21 +743,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         // Tile t+1 has landed: vmcnt retires in issue order and the only vector-memory operations issued after tile t+1's DMA are
         // tile t-1's two stores, tile t+2's five DMAs and tile t's two stores (every wave issues exactly these, unconditionally).
         // (ADD: eight atomics per tile where the other instance has two stores - 8 + 5 + 8)
-#if CM3P_FTRACE
-        const unsigned long long ft1 = __builtin_amdgcn_s_memtime();
-#endif
         if constexpr (ADD) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-#if CM3P_FTRACE
-        const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
-#endif
         if constexpr ((CM3P_FABL & 1) == 0) lds_barrier();
-#if CM3P_FTRACE
-        const unsigned long long ft3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ft_acc[0] += ft2 - ft1;
-        ft_acc[1] += ft3 - ft2;
-#endif
         step(I0{}, I1{}, WB{}, I0{}, WA{}, I0{}, I1{}, WA{}, I4{}, sA, dpA, sB, dpB, nst, nst, nullptr, post_hook);
         step(I1{}, I0{}, WB{}, I0{}, WA{}, I4{}, I0{}, WA{}, I8{}, sB, dpB, sA, dpA, nullptr, nullptr, nst, no_hook);
     };
@@ -695,14 +781,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     for (int i = 0; i < 16; ++i) dq[i] = 0.f;
     load_dq_operand(dqB0, 1, 8);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the only place a result is read right behind its asm MFMA chain)
+    // a step ends with the first eight exponentials of the block its successor differentiates (see the slices in step()): the first block's here
+    if constexpr ((CM3P_FABL & 64) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sA[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(PRE ? sA[i] : sA[i] * cm), 0.f, 1.f);
+    }
     CM3P_SB();
 
     // No exit edge inside the unrolled ring (the accumulators never change registers): the tiles past the sequence re-read its last
     // rows with -inf score offsets (p = 0: exact zeros everywhere).  Epoch n_tiles (the second half of the last tile) is stored
     // in tile n_tiles + 1, hence the bound.
-#if CM3P_FTRACE
-    const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
-#endif
     for (int t = 0; t < n_tiles + 2; t += kFUnroll) {
         tile(std::integral_constant<int, 0>{}, I0{}, t);
         tile(std::integral_constant<int, 1>{}, I1{}, t + 1);
@@ -712,16 +800,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         tile(std::integral_constant<int, 2>{}, I1{}, t + 5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
-#if CM3P_FTRACE
-    if (g_bwdf_trace && lane == 0) {
-        unsigned long long* o = g_bwdf_trace + (size_t)blockIdx.x * 16 + wid * 4;  // (1-D grid: decode_block)
-        o[0] = ft_acc[0];
-        o[1] = ft_acc[1];
-        o[2] = __builtin_amdgcn_s_memtime() - ft0;
-        o[3] = (unsigned long long)(n_tiles + 2 + kFUnroll - 1) / kFUnroll * kFUnroll;
-    }
-#endif
-
 
     // ---- epilogue: dK = scale * dK^T acc (inverse rotary applied), dV; keys under the padding mask get zeros
 #pragma unroll
@@ -858,13 +936,7 @@ int cm3p_attn_bwd_fused(const void* qkv, const void* out, const void* dout, cons
 }  // extern "C"
 
 // timing-only ablation switches this object was built with (0 in every shipped build: cm3p_build_ablation_flags, tests/test_cabi.py)
-int cm3p_ablation_flags_attention_bwd_fused() { return (CM3P_FABL) | ((CM3P_FTRACE) << 12); }
-#if CM3P_FTRACE
-extern "C" int cm3p_debug_set_bwdf_trace(unsigned long long* p) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwdf_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
-}
-#endif
-
+int cm3p_ablation_flags_attention_bwd_fused() { return (CM3P_FABL); }
 #if CM3P_DMA_AUDIT
 int cm3p_audit_set_attention_bwd_fused(void* buf) { return cm3p_audit_set_local(buf); }
 #endif
