@@ -34,13 +34,11 @@ def cost(ins: str) -> float:
     return 1.0
 
 
-def main():
-    args = [a for a in sys.argv[1:] if a != "-v"]
-    verbose = "-v" in sys.argv
-    isa = open(args[0]).read()
-    body = next(iter(isa_check.kernel_bodies(isa, args[1]).values()))
-    n_mfma = int(args[2])
-    seg = next(seg for _, seg in isa_check.loops(body) if seg.count("v_mfma") == n_mfma)
+def gap_costs(isa: str, kernel: str, n_mfma: int, which: int = 0):
+    """-> (gaps, cycles per MFMA): gaps = [(issue cycles, [opcodes])] of the `which`-th loop of `kernel` with n_mfma MFMAs, split at its MFMAs
+    (hot path: blocks that forward branches jump over are skipped)."""
+    body = next(iter(isa_check.kernel_bodies(isa, kernel).values()))
+    seg = [seg for _, seg in isa_check.loops(body) if seg.count("v_mfma") == n_mfma][which]
     lines = body.split("\n")
     first = body[:body.index(seg)].count("\n")
     hot = [l.strip().split(";")[0].strip() for _, l in isa_check.hot_path(lines, first, first + seg.count("\n")) if l.startswith("\t") and l.strip() and not l.strip().startswith(";")]
@@ -53,6 +51,13 @@ def main():
         cur += cost(ins)
         names.append(ins.split()[0])
     gaps.append((cur, names))
+    return gaps, mfma_cyc
+
+
+def main():
+    args = [a for a in sys.argv[1:] if a != "-v"]
+    verbose = "-v" in sys.argv
+    gaps, mfma_cyc = gap_costs(open(args[0]).read(), args[1], int(args[2]))
     tot_issue = sum(g for g, _ in gaps)
     tot_run = sum(max(mfma_cyc, g) for g, _ in gaps)
     print(f"{len(gaps)} MFMA gaps; issue sum {tot_issue:.0f} = {tot_issue / len(gaps):.1f} per MFMA; as placed sum(max({mfma_cyc:.0f}, gap)) = {tot_run:.0f} = {tot_run / len(gaps):.1f} per MFMA; "
