@@ -20,10 +20,14 @@ Extra objects on that line:
   cpu_baseline  the CPU oracle (oracle/cm3p_oracle.py: the reference's fp32 sdpa path restated) timed on the host's cores on
                 a bounded sample of the same workload (B = 2 at the real sequence lengths, 1 warm-up +
                 2 timed iterations), rank 0 at N = 1 only.
-  secondary     N = 1 only: BASELINE configs[3] ("C4": beatmap seq 8192, batch 16) timed for 3 steps after the judged region,
-                so the north-star target (fraction of bf16 MFMA peak on fwd+bwd at seq 8192) is observed by the same run.
+  secondary     N = 1 only: BASELINE configs[3] ("C4": beatmap seq 8192, batch 16) timed for --secondary-steps (10) steps after 3
+                warm-up steps behind the judged region, so the north-star target (fraction of bf16 MFMA peak on fwd+bwd at seq 8192)
+                is a first-class measurement of the same run (r05 verdict item 5: it used to be 3 steps after 2).
   comm          N > 1 only: the step re-timed without the gradient all-reduce (DDP no_sync) and without the embedding
-                all-gather -> exposed_allreduce_ms / exposed_allgather_ms per step (max over ranks).
+                all-gather -> exposed_allreduce_ms / exposed_allgather_ms per step (max over ranks).  These legs and the
+                per-rank times run behind a deadline on rank 0 (CM3P_BENCH_DIAG_DEADLINE_S, 300 s): if a diagnostic collective
+                never returns, the judged line - complete before any of them started - is printed without them.  The leg that
+                needs a second DDP wrapper (bf16 all-reduce A/B) runs only with --diagnose.
   replicas      N > 1 only: after the warm-up every rank's parameter gradients are check-summed bit for bit (int32 view, 64-bit
                 sum) and the checksums compared with one all-reduce: DDP must leave identical gradients on every rank, and the run
                 aborts (non-zero exit, rank named) if it does not; per-rank peak device memory and the attention workspace size.
@@ -239,13 +243,17 @@ def roofline_object(tag: str, timed_launches, bracketed_step: dict, workload: st
     achieved = work / (ms * 1e-3) / scale if ms > 0 else 0.0
     traffic, traffic_file = pmc_value("traffic", workload, tag)
     busy, busy_file = pmc_value("mfma_util", workload, tag)
-    clock, _ = pmc_value("mfma_util", workload, tag, "clock_ghz")  # (GRBM_GUI_ACTIVE / 8 / duration of the same counter pass)
+    clock, clock_file = pmc_value("mfma_util", workload, tag, "clock_ghz")  # (GRBM_GUI_ACTIVE / 8 / duration of the same counter pass)
     held = {}
     if not hbm_bound and clock:
         # `frac` stays against the nominal peak (2.4 GHz); the part lowers its clock under matrix load (MI355X_MICROARCH.md "DVFS give-back",
-        # DESIGN.md section 4 r05: an MFMA-only stream of the attention forward holds 1.94 GHz), so the same rate against the peak AT the clock
-        # this kernel held is reported beside it - information, not the judged number
-        held = {"clock_ghz": round(clock, 3), "frac_at_held_clock": achieved / (peak * clock / NOMINAL_CLOCK_GHZ)}
+        # DESIGN.md section 4: an MFMA-only stream of the attention forward holds 1.94 GHz), so the same rate against the peak AT the clock
+        # this kernel held is reported beside it - information, not the judged number.  The clock is NOT this run's: it comes from the
+        # committed counter pass named in clock_source (another run of the same command, under the profiler, possibly another box; boxes
+        # spread about +-1.5 %), so the quotient mixes two measurements and is labelled as such (r05 advisor).
+        held = {"clock_ghz": round(clock, 3), "clock_source": clock_file,
+                "clock_provenance": "GRBM_GUI_ACTIVE / 8 / kernel duration of a committed rocprofv3 counter pass of this command - a profiled run, not this one",
+                "frac_at_held_clock": achieved / (peak * clock / NOMINAL_CLOCK_GHZ)}
     return {
         "kernel": tag, "bound": "hbm" if hbm_bound else "mfma", "achieved": achieved, "peak": peak, "unit": unit,
         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_file,
@@ -258,7 +266,9 @@ def roofline_object(tag: str, timed_launches, bracketed_step: dict, workload: st
 
 
 def scaling_diagnosis(args, world, rank, device, model, step, timed, n, my_ms, ms_per_step, backend):
-    """N > 1 only, all OUTSIDE the judged region: what a single scaling run needs to say besides its one number (r04 verdict item 3).
+    """N > 1 only, all OUTSIDE the judged region and BEHIND the deadline of main() (a diagnostic that hangs cannot cost the run its judged
+    line): what a single scaling run needs to say besides its one number (r04 verdict item 3).  The leg that builds a second DDP wrapper
+    (b) runs only with --diagnose (r05 advisor: it had never executed over RCCL).
     The step is re-timed (a) with a surplus grid for the ring-kernel GEMMs - 1024 workgroups instead of one per CU, the arrangement
     that loses least while RCCL's channel workgroups hold CUs (+7..10 % per GEMM against +26..58 %) - and (b) with the
     gradient all-reduce in bf16 (a second DDP wrapper around the same module with bf16_compress_hook); together with the no_sync / rank-local
@@ -279,7 +289,7 @@ def scaling_diagnosis(args, world, rank, device, model, step, timed, n, my_ms, m
     # (the surplus-grid A/B of the ring-kernel GEMMs is taken in the warm-up, where its winner is selected: comm.gemm_grid)
     # bf16 gradient all-reduce (skipped when the judged run already used it); every rank takes the same path: an unsupported dtype
     # raises on all of them at the same collective
-    if args.grad_compress == "none":
+    if args.grad_compress == "none" and args.diagnose:
         try:
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
 
@@ -355,6 +365,10 @@ def main():
     ap.add_argument("--padded", action="store_true", help="not the judged configuration: right-padded rows, valid length ~ U{S/2..S}")
     ap.add_argument("--unpad", action="store_true", help="with --padded: run the beatmap tower on the valid tokens only (unpadded execution)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C4 (seq 8192) line reported next to the judged C2 number at N = 1")
+    ap.add_argument("--secondary-steps", type=int, default=10, help="timed steps of the C4 (seq 8192) leg at N = 1 (after 3 warm-up steps)")
+    ap.add_argument("--diagnose", action="store_true",
+                    help="N > 1: also re-time the step through a second DDP wrapper with a bf16 all-reduce hook (scaling_diagnosis); off by default - "
+                         "the judged run keeps to the legs that only reuse the judged region's own collectives")
     ap.add_argument("--grad-compress", default="none", choices=["none", "bf16"],
                     help="N > 1: DDP communication hook (bf16 halves the 545 MB fp32 gradient all-reduce; off in the judged run)")
     args = ap.parse_args()
@@ -439,25 +453,15 @@ def main():
         # Replica consistency: after a DDP step every rank holds the SAME averaged gradients, bit for bit.
         if args.warmup == 0:
             step()
-        acc = torch.zeros((), dtype=torch.int64, device=device)
-        for p_ in model.parameters():
-            if p_.grad is not None:
-                acc += p_.grad.detach().contiguous().view(torch.int32).to(torch.int64).sum()
-        lo, hi = acc.clone(), acc.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         from cm3p_amd import kernels as _K
+        from cm3p_amd.dist import replica_report
 
-        mem = torch.tensor([float(torch.cuda.max_memory_allocated(device)), float(sum(t.numel() for t in _K._fused_ws.values()))],
-                           device=device, dtype=torch.float64)
-        mems = [torch.zeros_like(mem) for _ in range(world)]
-        dist.all_gather(mems, mem)
-        replicas = {"gradient_checksum": int(acc.item()), "identical_on_all_ranks": bool(lo.item() == hi.item()),
-                    "peak_memory_gb_per_rank": [round(m[0].item() / 2 ** 30, 2) for m in mems],
-                    "attention_workspace_gb_per_rank": [round(m[1].item() / 2 ** 30, 2) for m in mems]}
-        print(f"[bench] rank {rank}: gradient checksum {int(acc.item())} peak memory {mem[0].item() / 2 ** 30:.1f} GiB", file=sys.stderr, flush=True)
-        if lo.item() != hi.item():
-            raise RuntimeError(f"replicas diverged: gradient checksums differ across ranks (min {int(lo.item())}, max {int(hi.item())})")
+        replicas = replica_report(model.parameters(), device, float(torch.cuda.max_memory_allocated(device)),
+                                  float(sum(t.numel() for t in _K._fused_ws.values())))
+        print(f"[bench] rank {rank}: gradient checksum {replicas['gradient_checksum']} peak memory "
+              f"{replicas['peak_memory_gb_per_rank'][rank]:.1f} GiB", file=sys.stderr, flush=True)
+        if not replicas["identical_on_all_ranks"]:
+            raise RuntimeError(f"replicas diverged: gradient checksums differ across ranks (min {replicas['checksum_min']}, max {replicas['checksum_max']})")
 
     def fence():
         torch.cuda.synchronize()
@@ -488,14 +492,14 @@ def main():
     if world > 1:
         from cm3p_amd import kernels as _K
 
+        from cm3p_amd.dist import choose_gemm_grid
+
         g0 = _K.gemm8p_get_grid()
         ms_g0 = timed(step, 2)
         _K.gemm8p_set_grid(1024)
         ms_g1 = timed(step, 2)
-        use_surplus = g0 == 0 and backend == "nccl" and ms_g1 < 0.99 * ms_g0
-        _K.gemm8p_set_grid(1024 if use_surplus else g0)
-        grid_choice = {"candidates": {"one per CU" if g0 == 0 else str(g0): ms_g0, "1024": ms_g1}, "selected": 1024 if use_surplus else (g0 or "one per CU"),
-                       "rule": "1024 workgroups if >= 1 % faster over RCCL, measured in the warm-up (2 steps each, max over ranks)"}
+        grid_choice = choose_gemm_grid(g0, ms_g0, ms_g1, backend)  # (both times are max-over-ranks: every rank takes the same decision)
+        _K.gemm8p_set_grid(grid_choice["grid"])
 
     # Per-kernel timing.  One extra UNTIMED step with a HIP-event pair around every C-ABI call gives the breakdown and names the
     # dominant single kernel; inside the timed region only every third launch of that kernel is bracketed (every launch of every
@@ -529,6 +533,66 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     pairs_per_s = world * w["B"] * args.steps / elapsed
+    flops = step_flops(config, w)
+
+    def judged_line(extra=None):
+        """The contract's keys: everything the judged region measured.  Built BEFORE any diagnostic leg runs."""
+        d = {
+            "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",
+            "value": pairs_per_s,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "steps_per_s": 1e3 / ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "global_batch": world * w["B"], "beatmap_seq": w["S"],
+                       "metadata_seq": w["L"], "parallelism": f"dp{world}" + ("+allgather-negatives" if world > 1 else ""),
+                       "weights": "random init (reference init rules), fp32 master / bf16 GEMM operands", "loss": float(loss.item()),
+                       **({"valid_token_fraction": w["valid_token_fraction"]} if "valid_token_fraction" in w else {})},
+            "step_tflops_algorithmic": flops / 1e12,
+            "step_mfma_frac": flops / (ms_per_step * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+        }
+        if rank == 0 and prof:
+            # dominant SINGLE kernel (tags of C-ABI calls that launch several kernels are listed in the breakdown only, so
+            # that the figure can be checked against one row of the rocprofv3 --stats summary); its launches were timed with
+            # HIP events inside the timed region, on the stream they run on
+            d["roofline"] = roofline_object(dom_tag, prof[dom_tag], prof_all, args.workload)
+            d["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])[:12]}
+            d["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
+            # the streaming kernels against the HBM roofline (north star: "rocprof HBM GB/s ... vs gfx950 peak"): algorithmic bytes per launch
+            # (what one pass must read and write) / the launch's duration in that bracketed step, both towers' launches averaged
+            d["hbm_kernels"] = hbm_rows(prof_all)
+        if replicas is not None:
+            d["replicas"] = replicas
+        d.update(extra or {})
+        return d
+
+    result = judged_line()
+    # N > 1: everything from here to the print is diagnostics (more collectives, on a code path the judged region did not take).  A rank
+    # that hangs in one of them must not cost the run its number: rank 0 arms a deadline; when it fires, the judged line goes out as it
+    # stands (with comm.diagnosis_error saying so) and the process ends - the launcher then tears the other ranks down.
+    deadline = None
+    if world > 1 and rank == 0:
+        import threading
+
+        def _give_up():
+            print(f"[bench] rank 0: diagnostics did not return within {deadline_s} s - printing the judged line without them", file=sys.stderr, flush=True)
+            # (the text was made before the first diagnostic ran: nothing here may touch the GPU or a collective, which is what may be stuck)
+            print(judged_text, flush=True)
+            os._exit(0)
+
+        deadline_s = int(os.environ.get("CM3P_BENCH_DIAG_DEADLINE_S", "300"))
+        judged_text = json.dumps({**result, "comm": {"diagnosis_error": f"deadline of {deadline_s} s passed before the diagnostic legs returned",
+                                                     "gemm_grid": grid_choice}})
+        deadline = threading.Timer(deadline_s, _give_up)
+        deadline.daemon = True
+        deadline.start()
     comm = None
     if world > 1:
         # SURVEY.md section 8(d) step-time split: the same step without the gradient all-reduce (DDP no_sync), then also without
@@ -552,47 +616,14 @@ def main():
             comm.update(scaling_diagnosis(args, world, rank, device, model, step, timed, n_comm, elapsed_local / args.steps * 1e3, ms_per_step, backend))
         except Exception as e:  # noqa: BLE001
             comm["diagnosis_error"] = f"{type(e).__name__}: {e}"[:300]
-    flops = step_flops(config, w)
-    result = {
-        "metric": "contrastive training steps/sec (global beatmap-metadata pairs/sec)",
-        "value": pairs_per_s,
-        "unit": "pairs/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "steps_per_s": 1e3 / ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "bf16",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {w['desc']}", "global_batch": world * w["B"], "beatmap_seq": w["S"],
-                   "metadata_seq": w["L"], "parallelism": f"dp{world}" + ("+allgather-negatives" if world > 1 else ""),
-                   "weights": "random init (reference init rules), fp32 master / bf16 GEMM operands", "loss": float(loss.item()),
-                   **({"valid_token_fraction": w["valid_token_fraction"]} if "valid_token_fraction" in w else {})},
-        "step_tflops_algorithmic": flops / 1e12,
-        "step_mfma_frac": flops / (ms_per_step * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-    }
     if not args.no_optimizer:
         opt_info = optimizer_leg(model)  # every rank steps (replicas must stay identical); rank 0 reports
         if rank == 0:
             result["optimizer_step"] = opt_info
-    if rank == 0:
-        if prof:
-            # dominant SINGLE kernel (tags of C-ABI calls that launch several kernels are listed in the breakdown only, so
-            # that the figure can be checked against one row of the rocprofv3 --stats summary); its launches were timed with
-            # HIP events inside the timed region, on the stream they run on
-            result["roofline"] = roofline_object(dom_tag, prof[dom_tag], prof_all, args.workload)
-            result["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])[:12]}
-            result["kernel_breakdown_source"] = "one extra untimed step with every launch bracketed by HIP events"
-            # the streaming kernels against the HBM roofline (north star: "rocprof HBM GB/s ... vs gfx950 peak"): algorithmic bytes per launch
-            # (what one pass must read and write) / the launch's duration in that bracketed step, both towers' launches averaged
-            result["hbm_kernels"] = hbm_rows(prof_all)
-        if comm is not None:
-            result["comm"] = comm
-        if replicas is not None:
-            result["replicas"] = replicas
+    if deadline is not None:
+        deadline.cancel()
+    if rank == 0 and comm is not None:
+        result["comm"] = comm
     if world == 1 and args.workload == "c2" and not args.no_secondary and not args.padded and not args.batch:
         # BASELINE configs[3] next to the judged number: the north-star target is quoted at seq 8192
         w4 = dict(WORKLOADS["c4"])
@@ -610,13 +641,17 @@ def main():
             dom4 = max((priced4 or prof4_all).items(), key=lambda kv: kv[1][1])[0]
             fence()
             _lib.profile_begin(only=dom4, every=PROFILE_EVERY)  # ... whose launches are then timed live inside the timed steps
-        ms4 = timed(step, 3)
+        for _ in range(2):  # with the first step above and the bracketed one: >= 3 warm-up steps at this shape
+            step()
+        n4 = max(1, args.secondary_steps)
+        ms4 = timed(step, n4)
         prof4 = _lib.profile_end() if profile else {}
         f4 = step_flops(config, w4)
-        result["secondary"] = {"workload": f"c4: {w4['desc']}", "steps": 3, "warmup": 1 + int(profile), "ms_per_step": ms4,
+        result["secondary"] = {"workload": f"c4: {w4['desc']}", "steps": n4, "warmup": 3 + int(profile), "ms_per_step": ms4,
                                "value": w4["B"] / (ms4 * 1e-3),
                                "unit": "pairs/s", "step_tflops_algorithmic": f4 / 1e12,
-                               "step_mfma_frac": f4 / (ms4 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "target_mfma_frac": 0.40}
+                               "step_mfma_frac": f4 / (ms4 * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "target_mfma_frac": 0.40,
+                               "target_ms_per_step": f4 / (0.40 * BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
         if prof4.get(dom4):
             result["secondary"]["roofline"] = roofline_object(dom4, prof4[dom4], prof4_all, "c4")
             result["secondary"]["kernel_breakdown_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(prof4_all.items(), key=lambda kv: -kv[1][1])[:12]}

@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -49,6 +49,7 @@ SIGNATURES = {
     "cm3p_rope_table": [_P, _L, _P, _I, _P, _P, _P],
     "cm3p_rope_apply": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
     "cm3p_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "cm3p_attn_fwd_impl": [_I, _I, _I, _I],
     "cm3p_attn_probs": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "cm3p_attn_generic_supported": [_I],
     "cm3p_attn_fwd_generic": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],

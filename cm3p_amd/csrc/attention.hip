@@ -741,10 +741,14 @@ static bool fwd_pipelined() {  // (read per call: the tests run both in one proc
     return !(e && e[0] == 'w');
 }
 
+// the routing rule, also exported (cm3p_attn_fwd_impl): (TileDma::rows: 32-bit row * pitch source offsets, attn_common.h)
+static bool fwd_takes_pipelined(int S, int nh, int window, int pre) {
+    return window < 0 && pre && fwd_pipelined() && (int64_t)S * 3 * nh * 128 < (int64_t(1) << 31);
+}
+
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                            float scale, VarLen vl, int pre, hipStream_t s) {
-    // (TileDma::rows: 32-bit row * pitch source offsets, attn_common.h)
-    if (window < 0 && pre && fwd_pipelined() && (int64_t)S * 3 * nh * 128 < (int64_t(1) << 31))
+    if (fwd_takes_pipelined(S, nh, window, pre))
         return cm3p_launch_attn_fwd_global(qkv, out, lse, key_mask, B, S, nh, vl.cu, vl.total, s);
     // QSUB = 1 (32 queries per wave, 3 waves per SIMD) measured faster than QSUB = 2 (64 per wave, compiler-scheduled):
     // 2.29 ms vs 3.49 ms per C2 global layer.  The two-chain variant needs a hand-placed MFMA/VALU interleave to pay.
@@ -823,6 +827,8 @@ int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mas
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }
+
+int cm3p_attn_fwd_impl(int S, int nh, int window, int q_prescaled) { return fwd_takes_pipelined(S, nh, window, q_prescaled != 0) ? 1 : 0; }
 
 int cm3p_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                   const uint8_t* key_mask, int B, int S, int nh, int window, float scale, const float* cos_tab,

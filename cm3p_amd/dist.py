@@ -118,3 +118,34 @@ def warn_variations_stay_local():
         _warned_3d = True
         warnings.warn("CM3PModel.gather_negatives is set but metadata_ids is (B, V, L): metadata variations are rank-local "
                       "negatives; this batch is scored without cross-rank gathering.", RuntimeWarning, stacklevel=3)
+
+
+# ---- what a multi-rank run says about itself (bench.py; device agnostic, so that world sizes one card cannot host are rehearsed over gloo
+# on CPU tensors: tests/test_dist_gloo.py runs both at world 8)
+def replica_report(parameters, device, peak_memory_bytes: float = 0.0, workspace_bytes: float = 0.0, group=None) -> dict:
+    """After a DDP step every rank must hold the SAME averaged gradients, bit for bit: check-sum every rank's
+    gradients (int32 view, 64-bit sum), compare the sums with one MIN and one MAX all-reduce, gather per-rank memory figures."""
+    world = dist.get_world_size(group)
+    acc = torch.zeros((), dtype=torch.int64, device=device)
+    for p in parameters:
+        if p.grad is not None:
+            acc += p.grad.detach().contiguous().view(torch.int32).to(torch.int64).sum()
+    lo, hi = acc.clone(), acc.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    mem = torch.tensor([peak_memory_bytes, workspace_bytes], device=device, dtype=torch.float64)
+    mems = [torch.zeros_like(mem) for _ in range(world)]
+    dist.all_gather(mems, mem, group=group)
+    return {"gradient_checksum": int(acc.item()), "identical_on_all_ranks": bool(lo.item() == hi.item()),
+            "checksum_min": int(lo.item()), "checksum_max": int(hi.item()),
+            "peak_memory_gb_per_rank": [round(m[0].item() / 2 ** 30, 2) for m in mems],
+            "attention_workspace_gb_per_rank": [round(m[1].item() / 2 ** 30, 2) for m in mems]}
+
+
+def choose_gemm_grid(default_grid: int, ms_default: float, ms_surplus: float, backend: str) -> dict:
+    """The grid of the ring-kernel GEMMs at N > 1, from two warm-up timings that are already the MAX over ranks (so every rank decides
+    alike): 1024 workgroups when that is >= 1 % faster over RCCL (whose channel workgroups hold CUs), else what was set (0 = one per CU)."""
+    use_surplus = default_grid == 0 and backend == "nccl" and ms_surplus < 0.99 * ms_default
+    return {"candidates": {"one per CU" if default_grid == 0 else str(default_grid): ms_default, "1024": ms_surplus},
+            "selected": 1024 if use_surplus else (default_grid or "one per CU"), "grid": 1024 if use_surplus else default_grid,
+            "rule": "1024 workgroups if >= 1 % faster over RCCL, measured in the warm-up (2 steps each, max over ranks)"}

@@ -299,9 +299,10 @@ def gemm8p_get_grid() -> int:
 
 
 def _attn_fwd_name(window: int, prescaled: bool, masked: bool, S: int, nh: int) -> str:
-    """The forward kernel a call lands on, as rocprofv3 names it (csrc/attention.hip: launch_attn_fwd): global layers with pre-scaled q run
-    the pipelined kernel of csrc/attention_fwd.hip unless CM3P_ATTN_FWD_IMPL=wave3 (or the sequence is too long for its 32-bit row offsets)."""
-    if window < 0 and prescaled and os.environ.get("CM3P_ATTN_FWD_IMPL", "")[:1] != "w" and S * 3 * nh * 128 < (1 << 31):
+    """The forward kernel a call lands on, as rocprofv3 names it.  The routing is the library's (cm3p_attn_fwd_impl: global layers with
+    pre-scaled q run the pipelined kernel of csrc/attention_fwd.hip unless CM3P_ATTN_FWD_IMPL=wave3 or the sequence is too long for its
+    32-bit row offsets); this function only spells the answer (r05 advisor: it used to re-derive the rule)."""
+    if query("cm3p_attn_fwd_impl", S, nh, window, int(prescaled)):
         return "attn_fwd_g_kernel<4, " + ("true>" if masked else "false>")
     return "attn_fwd_kernel<1, %s, " + ("true>" if window >= 0 else "false>")
 

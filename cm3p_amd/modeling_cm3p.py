@@ -6,10 +6,11 @@ submodule / state-dict names and Auto* registration, so `train.py` drives it unc
 All arithmetic runs in libcm3p_hip.so through autograd nodes defined here and in encoder.py; there is no PyTorch-op
 fallback and inputs must live on the GPU.
 
-Scope: CM3PModel's contrastive branch with both towers and the audio front end, plus the first "next"
-row: CM3PModel's MLM head (`has_decoder_head`, loss_type "ForMaskedLM": `loss += 0.5 * mlm_loss`, the v7 recipe).  The
-stand-alone variants (`CM3PForMaskedLM`, `CM3PForBeatmapClassification`, `*WithProjection`) are later rows: importable,
-but they raise NotImplementedError when constructed.
+Scope: CM3PModel's contrastive branch with both towers and the audio front end, plus the "next" rows:
+CM3PModel's MLM head (`has_decoder_head`, loss_type "ForMaskedLM": `loss += 0.5 * mlm_loss`, the v7 recipe), padded AND
+unpadded ("varlen") execution of the towers, and the stand-alone variants the reference's train.py imports
+(`CM3PForMaskedLM`, `CM3PForBeatmapClassification`, `CM3PBeatmapModelWithProjection`, `CM3PMetadataModelWithProjection`),
+all implemented on the same kernels below.
 """
 from __future__ import annotations
 
@@ -709,8 +710,11 @@ class CM3PModel(CM3PPreTrainedModel):
         output_logits: Optional[bool] = None,
         **kwargs,
     ) -> CM3POutput:
-        """Contrastive forward (ref:cm3p/modeling_cm3p.py:849-1012).  Padded batches only: whatever `attn_implementation`
-        says, attention runs in the HIP flash kernels and no host-side unpadding is needed."""
+        """Contrastive forward (ref:cm3p/modeling_cm3p.py:849-1012).  Whatever `attn_implementation` says, attention runs in the
+        HIP flash kernels, which take the key-padding mask as it is: padded batches need no host-side unpadding.  Unpadded
+        execution is supported as well - `self.unpad_inputs = True` packs the valid tokens of a padded batch, and a caller may hand
+        over rows it has unpadded itself (`indices` / `cu_seqlens` / `max_seqlen` / `batch_size` / `seq_len`, the arguments of the
+        reference's flash_attention_2 branch, ref:cm3p/modeling_cm3p.py:911-931) - with the same results."""
         output_logits = output_logits if output_logits is not None else self.config.has_decoder_head
         if metadata_ids is not None and metadata_ids.dim() == 3 and return_loss and metadata_variation_classes is None:
             raise ValueError("When providing multiple metadata variations, metadata_variation_classes must be provided in order to compute loss correctly.")

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 15
+#define CM3P_ABI_VERSION 16
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -203,6 +203,10 @@ int cm3p_rope_apply(void* qkv, const float* cos_tab, const float* sin_tab, int B
  * extra multiply per score) - q is never re-rounded to bf16 either way.  `scale` is always the softmax scale (1 / sqrt(64)). */
 int cm3p_attn_fwd(const void* qkv, void* out, float* lse, const uint8_t* key_mask, int B, int S, int nh, int window,
                   float scale, int q_prescaled, void* stream);
+/* Host-only: which forward kernel cm3p_attn_fwd / cm3p_attn_fwd_varlen launches for this call - 1: the pipelined global kernel of
+ * csrc/attention_fwd.hip (window < 0, pre-scaled q, row offsets within 32 bits, CM3P_ATTN_FWD_IMPL not "wave3"), 0: attn_fwd_kernel of
+ * csrc/attention.hip.  The ONE place the routing is decided; callers that label launches (profiler tags) ask instead of re-deriving it. */
+int cm3p_attn_fwd_impl(int S, int nh, int window, int q_prescaled);
 
 /* output_attentions: the attention probabilities [B, nh, S, S] fp32 of one layer from qkv and the lse cm3p_attn_fwd stored - what
  * the reference returns as `attentions` (TF switches to eager_attention_forward for such a call,

@@ -70,7 +70,7 @@ def _worker(rank, world, port, b, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b", [(2, 3), (2, 1), (4, 2)])  # 2 and 4 processes
+@pytest.mark.parametrize("world,b", [(2, 3), (2, 1), (4, 2), (8, 1), (8, 4)])  # 2 and 4 processes; 8 = the node C3 / C5 run on
 def test_gathered_loss_and_grads_equal_single_process_reference(world, b):
     from oracle import cm3p_oracle as O
 
@@ -90,3 +90,46 @@ def test_gathered_loss_and_grads_equal_single_process_reference(world, b):
         assert abs(lmean.item() - ref_loss.item()) <= 1e-6
         for k, p in params.items():
             assert torch.allclose(grads[k], p.grad, atol=1e-6, rtol=1e-5), (rank, k, (grads[k] - p.grad).abs().max())
+
+
+def _report_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cm3p_amd.dist import choose_gemm_grid, replica_report
+
+        g = torch.Generator().manual_seed(5)
+        ps = [torch.nn.Parameter(torch.randn(7, 5, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g)), torch.nn.Parameter(torch.zeros(3))]
+        ps[0].grad, ps[1].grad = torch.randn(7, 5, generator=g), torch.randn(11, generator=g)  # (ps[2] has no gradient: skipped)
+        same = replica_report(ps, torch.device("cpu"), float(2 ** 30 * (rank + 1)), float(2 ** 29))
+        if rank == world - 1:
+            ps[1].grad[3] += 1e-7  # one rank one ulp-scale off: the bit-level sum must notice
+        diverged = replica_report(ps, torch.device("cpu"))
+        # the grid vote: every rank is handed the same (max-over-ranks) times and must come to the same answer
+        t = torch.tensor([100.0 + rank, 98.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[rank] = (same, diverged, choose_gemm_grid(0, float(t[0]), float(t[1]), "nccl"), choose_gemm_grid(0, float(t[0]), float(t[1]), "gloo"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_replica_report_and_grid_vote_at_world_size(world):
+    """bench.py's N > 1 bookkeeping on CPU tensors over gloo (one card cannot host 8 ranks): the bit-level gradient checksum agrees on
+    identical replicas and notices a single differing element on one rank; the per-rank memory list has one entry per rank in rank
+    order; the GEMM-grid vote gives every rank the same decision."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_report_worker, args=(world, port, out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))
+    for rank in range(world):
+        same, diverged, vote_rccl, vote_gloo = out[rank]
+        assert same["identical_on_all_ranks"] is True and same["checksum_min"] == same["checksum_max"] == same["gradient_checksum"]
+        assert same["peak_memory_gb_per_rank"] == [float(r + 1) for r in range(world)]
+        assert same["attention_workspace_gb_per_rank"] == [0.5] * world
+        assert diverged["identical_on_all_ranks"] is False and diverged["checksum_min"] != diverged["checksum_max"]
+        assert vote_rccl == out[0][2] and vote_gloo == out[0][3]
+        assert vote_rccl["selected"] == 1024 and vote_rccl["grid"] == 1024  # 98 + (world - 1) against 100 + (world - 1): >= 1 % faster
+        assert vote_gloo["selected"] == "one per CU" and vote_gloo["grid"] == 0  # (the surplus grid is an answer to RCCL's channels only)

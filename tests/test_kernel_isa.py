@@ -46,9 +46,10 @@ def test_fused_checker_rejects_a_spill(isa):
 
 def test_issue_cost_walk_of_the_attention_streams(isa):
     """tools/isa_gapcost.py prices every MFMA gap of a hand-placed stream (v_exp 8, v_cvt_pk_bf16_f32 8 - tools/ubench/mfma_cvt_dep.hip -,
-    other VALU 4 ...).  Pins what DESIGN.md section 4 r05 says the walk shows: the fused backward issues ~32 cycles per MFMA in all but
-    places them unevenly (a quarter of its gaps nearly empty, a third over 40 cycles); the pipelined forward is issue-bound as a whole (more
-    than 40 cycles of issue per 32-cycle MFMA)."""
+    other VALU 4 ...).  Only what protects the kernels from regressing is asserted (r05 advisor: the earlier version also pinned the
+    schedule's documented UNEVENNESS as lower bounds, so that any improvement - or a hipcc bump - would have failed the suite): one priced
+    gap per MFMA of the loop body, and the issue cost per MFMA no higher than it is today.  What the walk shows beyond that (the share of
+    near-empty and over-full gaps) is a report: `python tools/isa_gapcost.py`."""
     import sys
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -56,10 +57,9 @@ def test_issue_cost_walk_of_the_attention_streams(isa):
 
     gaps, cyc = isa_gapcost.gap_costs(isa("attention_bwd_fused.hip"), "attn_bwd_fused_kernelILb1ELb0E", 480)
     per = [g for g, _ in gaps]
-    assert len(per) == 480 and cyc == 32.0
-    assert 30.0 <= sum(per) / 480 <= 34.0
-    assert 38.0 <= sum(max(32.0, g) for g in per) / 480 <= 43.0
-    assert sum(g < 16 for g in per) >= 100 and sum(g > 40 for g in per) >= 120
+    assert len(per) == 480 and cyc == 32.0          # gap count == MFMA count of the six-tile ring body
+    assert sum(per) / 480 <= 34.0                   # issue work per MFMA
+    assert sum(max(32.0, g) for g in per) / 480 <= 43.0  # ... and as placed (a gap cannot be shorter than its MFMA)
     gaps, cyc = isa_gapcost.gap_costs(isa("attention_fwd.hip"), "attn_fwd_g_kernelILi4ELb0E", 256)
     per = [g for g, _ in gaps]
-    assert len(per) in (256, 257) and 42.0 <= sum(per) / 256 <= 52.0  # (the rotated loop opens with a partial gap)
+    assert len(per) in (256, 257) and sum(per) / 256 <= 52.0  # (the rotated loop opens with a partial gap)

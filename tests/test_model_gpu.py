@@ -38,18 +38,28 @@ FIX_MEASURED: dict = {}
 try:
     import json as _json
 
-    FIX_BASE = _json.load(open(os.path.join(GOLD, "fixture_errors_r05.json")))["measured"]
+    _fix_file = _json.load(open(os.path.join(GOLD, "fixture_errors_r05.json")))
+    FIX_BASE = _fix_file["measured"]
+    FIX_BASE_TOOLCHAIN = _fix_file.get("toolchain")  # (absent in the r05 file: it was measured with the toolchain named below)
 except OSError:
-    FIX_BASE = {}
+    FIX_BASE, FIX_BASE_TOOLCHAIN = {}, None
+FIX_R05_TOOLCHAIN = {"hip": "7.0", "torch": "2.10.0+rocm7.0"}  # what tests/golden/fixture_errors_r05.json was measured with
+
+
+def _toolchain() -> dict:
+    return {"hip": ".".join(str(torch.version.hip or "").split(".")[:2]), "torch": torch.__version__}
 
 
 def _fix(tag: str, key: str, value: float, bound: str):
-    """records the error and asserts it against min(class bound, 3 x the committed measurement of this case and quantity)"""
+    """records the error and asserts it against min(class bound, 3 x the committed measurement of this case and quantity).  The tight
+    per-case bound is a SELF-measurement (one MI355X, one hipcc build; r05 advisor): it is floored at a tenth of the class bound -
+    quantities measured near 1e-6 would otherwise get an absolute bound a different FMA contraction can exceed with nothing wrong - and
+    applies only under the toolchain the file was measured with; any other toolchain is held to the class bound alone."""
     FIX_MEASURED.setdefault(tag, {})[key] = float(value)
     tol = FIX_TOL[bound]
     base = FIX_BASE.get(tag, {}).get(key)
-    if base is not None:
-        tol = min(tol, max(3.0 * base, 1e-5))
+    if base is not None and _toolchain() == (FIX_BASE_TOOLCHAIN or FIX_R05_TOOLCHAIN):
+        tol = min(tol, max(3.0 * base, 0.1 * FIX_TOL[bound]))
     assert value <= tol, f"{tag}: {key} = {value:.3e} > {tol:.2e}"
 
 
@@ -67,7 +77,7 @@ def _dump_fixture_errors():
                 b = "grad" if k.startswith("grad.") else k
                 worst[b] = max(worst.get(b, 0.0), v)
         with open(path, "w") as f:
-            json.dump(dict(tolerances=FIX_TOL, worst=worst, measured=FIX_MEASURED), f, indent=1, sort_keys=True)
+            json.dump(dict(tolerances=FIX_TOL, worst=worst, measured=FIX_MEASURED, toolchain=_toolchain()), f, indent=1, sort_keys=True)
     except OSError:
         pass
 
