@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
 
 // ---- reduce ---------------------------------------------------------------------------------------------------------------------
 // One 64-row tile of one (batch, head) by 256 threads: four threads per query row, each owns head dims [8j, 8j+8) and [32+8j, 32+8j+8).
-// The slabs are summed in key-block order, 16 at a time with all 32 loads of a thread in flight.
+// The slabs are summed in slab order, 8 at a time with all 16 loads of a thread in flight (r06: the batch was 16, but the step's shapes
+// have exactly 8 slabs per (batch, head) - 16 key blocks in pairs at S = 4096, 32 in fours at 8192 - so half of every thread's loads
+// were repeats of the last slab that were never summed; same sums in the same order).
 __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_part, uint16_t* __restrict__ dqkv, int t, int head, int b,
                                                int tid, const SeqView& sv, int Smax, int nh, float scale,
                                                const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
@@ -150,16 +152,17 @@ __device__ __forceinline__ void dq_reduce_tile(const uint16_t* __restrict__ dq_p
     float lo[8], hi[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) lo[i] = hi[i] = 0.f;
-    for (int kb0 = 0; kb0 < nkb_b; kb0 += 16) {
-        uint4 a[16], c[16];
+    constexpr int kBatch = 8;
+    for (int kb0 = 0; kb0 < nkb_b; kb0 += kBatch) {
+        uint4 a[kBatch], c[kBatch];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kBatch; ++u) {
             const int kb = min(kb0 + u, nkb_b - 1);  // (past the last block: a repeated load, not summed)
             a[u] = gload16<(CM3P_NT & 8) != 0>(p + kb * slab);
             c[u] = gload16<(CM3P_NT & 8) != 0>(p + kb * slab + 32);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kBatch; ++u) {
             if (kb0 + u < nkb_b) {
                 lo[0] += bf16lo(a[u].x), lo[1] += bf16hi(a[u].x), lo[2] += bf16lo(a[u].y), lo[3] += bf16hi(a[u].y);
                 lo[4] += bf16lo(a[u].z), lo[5] += bf16hi(a[u].z), lo[6] += bf16lo(a[u].w), lo[7] += bf16hi(a[u].w);
