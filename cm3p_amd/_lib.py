@@ -14,7 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_BF16, EPI_F32, EPI_F32_RESID, EPI_F32_BIAS = 0, 1, 2, 5
-ABI_VERSION = 17
+ABI_VERSION = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CM3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libcm3p_hip.so")  # env override: kernel experiments
@@ -38,9 +38,6 @@ SIGNATURES = {
     "cm3p_gemm_bf16": [_P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P],
     "cm3p_qkv_gemm_rope": [_P, _P, _P, _L, _L, _L, _P, _P, _I, _I, _I, _F, _P],
     "cm3p_gemm_wgrad_splits": [_L, _L, _L],
-    "cm3p_gemm_splitk_slabs": [_L, _I],
-    "cm3p_gemm_bf16_partials": [_P, _P, _P, _L, _L, _L, _L, _L, _I, _I, _I, _P],
-    "cm3p_reduce_many": [_I, _P, _P, _P, _P, _P, _P],
     "cm3p_gemm8p_set_grid": [_I],
     "cm3p_gemm8p_get_grid": [],
     "cm3p_build_ablation_flags": [],
@@ -240,11 +237,7 @@ def _launch(name: str, args):
             _check(fn(*[h if a is _STREAM else a for a in args]), name)
 
 
-def call(name: str, *args, tag: str | None = None, work: float | None = None, _anchor=None):
-    """_anchor: a device pointer that is NOT an argument of the entry point but names the GPU to launch on (entry points whose device
-    pointers travel inside host arrays)."""
-    if _anchor is not None:
-        return _call_anchored(name, args, tag, work, _anchor)
+def call(name: str, *args, tag: str | None = None, work: float | None = None):
     if _prof is None or (_prof_only is not None and (tag or name) not in _prof_only):
         _launch(name, args)
         return
@@ -260,13 +253,6 @@ def call(name: str, *args, tag: str | None = None, work: float | None = None, _a
     _launch(name, args)
     e1.record()
     _prof.append((tag or name, e0, e1, work))
-
-
-def _call_anchored(name, args, tag, work, anchor):
-    if anchor.dev == torch.cuda.current_device():
-        return call(name, *args, tag=tag, work=work)
-    with torch.cuda.device(anchor.dev):
-        return call(name, *args, tag=tag, work=work)
 
 
 def query(name: str, *args) -> int:

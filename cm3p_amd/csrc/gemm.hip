@@ -367,30 +367,9 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
     return CM3P_OK;
 }
 
-// k-split length and the number of slabs that results: a multiple of 128 where K allows it, so that every work item has an even
-// number of 64-deep k-tiles (gemm8p.hip's REBAL instances need that) - the last split absorbs the remainder, itself a multiple of 128 then
-static inline int64_t splitk_chunk(int64_t K, int split_k, int* slabs) {
-    if (split_k <= 1) {
-        *slabs = 1;
-        return K;
-    }
-    const int64_t q = (K % 128 == 0) ? 128 : BK;
-    const int64_t kchunk = ((K + split_k - 1) / split_k + q - 1) / q * q;
-    *slabs = (int)((K + kchunk - 1) / kchunk);
-    return kchunk;
-}
-
-int cm3p_gemm_splitk_slabs(int64_t K, int split_k) {
-    int slabs = 1;
-    if (K > 0 && split_k >= 1) splitk_chunk(K, split_k, &slabs);
-    return slabs;
-}
-
-// combine: run the fixed-order sum of the split-K slabs into C behind the GEMM (cm3p_gemm_bf16); otherwise the slabs are the result
-// (cm3p_gemm_bf16_partials: the caller combines them later, with the other reductions of its layer, in ONE cm3p_reduce_many launch)
-static int gemm_bf16_impl(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
-                          int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, bool combine, void* stream) {
-    CM3P_REQUIRE(A && B && (C || !combine) && M > 0 && N > 0 && K > 0);
+int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
+                   int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream) {
+    CM3P_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
     CM3P_REQUIRE((epilogue >= CM3P_EPI_BF16 && epilogue <= CM3P_EPI_F32_RESID) || (epilogue == CM3P_EPI_F32_BIAS && a_kc && b_kc));
     CM3P_REQUIRE(cm3p_aligned16(A) && cm3p_aligned16(B) && cm3p_aligned16(C));
     CM3P_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && N % 4 == 0);
@@ -400,10 +379,17 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const float* R,
     CM3P_REQUIRE((epilogue != CM3P_EPI_F32_RESID && epilogue != CM3P_EPI_F32_BIAS) || (R && cm3p_aligned16(R)));
     CM3P_REQUIRE(split_k >= 1 && (split_k == 1 || (epilogue == CM3P_EPI_F32 && workspace && cm3p_aligned16(workspace) && ldc == N)));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    int64_t kchunk = K;
     void* out = C;
     int64_t split_stride = 0;
-    const int64_t kchunk = splitk_chunk(K, split_k, &split_k);
-    if (split_k > 1 || !combine) {
+    if (split_k > 1) {
+        // k-split length: a multiple of 128 where K allows it, so that every work item has an even number of 64-deep k-tiles
+        // (gemm8p.hip's REBAL instances need that) - the last split absorbs the remainder, itself a multiple of 128 then
+        const int64_t q = (K % 128 == 0) ? 128 : BK;
+        kchunk = ((K + split_k - 1) / split_k + q - 1) / q * q;
+        split_k = (int)((K + kchunk - 1) / kchunk);
+    }
+    if (split_k > 1) {
         out = workspace;
         split_stride = M * N;
     }
@@ -416,7 +402,7 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const float* R,
     else rc = launch<false, false>(A, B, out, R, M, N, K, lda, ldb, ldc, epilogue, split_k, kchunk, split_stride, s);
     if (rc != CM3P_OK) return rc;
     CM3P_LAUNCH_CHECK();
-    if (split_k > 1 && combine) {
+    if (split_k > 1) {
         const int64_t n4 = M * N / 4;
         int64_t blocks = (n4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
@@ -424,17 +410,6 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const float* R,
         CM3P_LAUNCH_CHECK();
     }
     return CM3P_OK;
-}
-
-int cm3p_gemm_bf16(const void* A, const void* B, void* C, const float* R, int64_t M, int64_t N, int64_t K, int64_t lda,
-                   int64_t ldb, int64_t ldc, int a_kc, int b_kc, int epilogue, int split_k, float* workspace, void* stream) {
-    return gemm_bf16_impl(A, B, C, R, M, N, K, lda, ldb, ldc, a_kc, b_kc, epilogue, split_k, workspace, true, stream);
-}
-
-int cm3p_gemm_bf16_partials(const void* A, const void* B, float* workspace, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                            int a_kc, int b_kc, int split_k, void* stream) {
-    CM3P_REQUIRE(workspace && cm3p_aligned16(workspace) && split_k >= 1);
-    return gemm_bf16_impl(A, B, nullptr, nullptr, M, N, K, lda, ldb, N, a_kc, b_kc, CM3P_EPI_F32, split_k, workspace, false, stream);
 }
 
 int cm3p_gemm_geglu(const void* x, const void* w_interleaved, void* a, int64_t T, int64_t I, int64_t K, void* stream) {

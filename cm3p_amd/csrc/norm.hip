@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // 4 rounds of 8 loads per thread at 1024 partial rows, 16 in the 8-slice form of r01-r03: 17.6 -> ~6 us per launch);
 // slices are combined through LDS in slice order (deterministic).
 constexpr int kColsumSlices = 32;
-__device__ __forceinline__ void colsum_block(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H, int blk,
-                                             float (*red)[33]) {
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
+    __shared__ float red[kColsumSlices][33];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int col = blk * 32 + cx;
+    const int col = blockIdx.x * 32 + cx;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < H) {
         const int per = (nblk + kColsumSlices - 1) / kColsumSlices;
@@ -198,56 +198,6 @@ __device__ __forceinline__ void colsum_block(const float* __restrict__ partial, 
             for (int u = 0; u < 4; ++u) s4[u] += red[i + u][cx];
         }
         out[col] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    }
-}
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int H) {
-    __shared__ float red[kColsumSlices][33];
-    colsum_block(partial, out, nblk, H, blockIdx.x, red);
-}
-
-// ---- the reductions a layer's backward leaves behind, in ONE launch (r06; r05 verdict item 3) ------------------------------------
-// Every weight-gradient GEMM ends in a fixed-order sum of its split-K slabs and every LayerNorm backward in a column sum of its
-// per-workgroup partial rows: six launches of a few microseconds of work each per encoder layer, each one a full drain / refill of the
-// chip between two big kernels of the backward chain (170 launches, 4.1 ms of a C4 step in r05).  None of their results is read
-// before the layer's backward returns, so the producers now leave their partials in place (cm3p_gemm_bf16_partials,
-// cm3p_layernorm_bwd with dw == NULL) and this kernel combines all of them at the end of the layer: workgroup ranges per job, each
-// job summed exactly as its own kernel did (same order: bit-identical results).
-constexpr int kReduceMaxJobs = 8;
-struct ReduceJobs {
-    const float* src[kReduceMaxJobs];
-    float* dst[kReduceMaxJobs];
-    int64_t n[kReduceMaxJobs];    // kind 0: floats per slab (a multiple of 4); kind 1: columns H
-    int parts[kReduceMaxJobs];    // kind 0: slabs; kind 1: partial rows
-    int kind[kReduceMaxJobs];     // 0: out[i] = sum_z src[z * n + i] in slab order; 1: out[c] = colsum of src[parts][n] (colsum_block's order)
-    int block0[kReduceMaxJobs + 1];
-    int njobs;
-};
-__global__ __launch_bounds__(1024) void reduce_many_kernel(ReduceJobs J) {
-    __shared__ float red[kColsumSlices][33];
-    int j = 0;
-    while (j + 1 < J.njobs && (int)blockIdx.x >= J.block0[j + 1]) ++j;  // (workgroup-uniform)
-    const int blk = blockIdx.x - J.block0[j], nblk = J.block0[j + 1] - J.block0[j];
-    if (J.kind[j] == 1) {
-        colsum_block(J.src[j], J.dst[j], J.parts[j], (int)J.n[j], blk, red);
-        return;
-    }
-    const int64_t n4 = J.n[j] / 4;
-    const int splits = J.parts[j];
-    const f32x4* __restrict__ ws = reinterpret_cast<const f32x4*>(J.src[j]);
-    f32x4* __restrict__ out = reinterpret_cast<f32x4*>(J.dst[j]);
-    for (int64_t i = (int64_t)blk * 1024 + threadIdx.x; i < n4; i += (int64_t)nblk * 1024) {
-        f32x4 s = ws[i];
-        int z = 1;
-        for (; z + 4 <= splits; z += 4) {  // four slabs in flight, added in slab order (the order of splitk_reduce_kernel)
-            const f32x4 a = ws[i + (int64_t)z * n4], b = ws[i + (int64_t)(z + 1) * n4], c = ws[i + (int64_t)(z + 2) * n4],
-                        d = ws[i + (int64_t)(z + 3) * n4];
-            s += a;
-            s += b;
-            s += c;
-            s += d;
-        }
-        for (; z < splits; ++z) s += ws[i + (int64_t)z * n4];
-        out[i] = s;
     }
 }
 
@@ -744,7 +694,7 @@ int cm3p_layernorm_bwd_blocks(int64_t rows) { return ln_bwd_grid(rows); }
 int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* weight, const float* mean, const float* rstd,
                        const float* dres, float* dx_f32, void* dx_bf16, float* dw_partial, float* dw, int64_t rows, int H,
                        void* stream) {
-    CM3P_REQUIRE(dy && x && weight && mean && rstd && dw_partial && (dx_f32 || dx_bf16));
+    CM3P_REQUIRE(dy && x && weight && mean && rstd && dw_partial && dw && (dx_f32 || dx_bf16));
     CM3P_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 2048);
     CM3P_REQUIRE(dy_dtype == CM3P_F32 || dy_dtype == CM3P_BF16);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -758,34 +708,7 @@ int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
     CM3P_NC_SWITCH(H, CM3P_LN_BWD)
 #undef CM3P_LN_BWD
     CM3P_LAUNCH_CHECK();
-    if (dw) {  // (NULL: the caller sums dw_partial's cm3p_layernorm_bwd_blocks(rows) rows later, cm3p_reduce_many kind 1)
-        colsum_kernel<<<(H + 31) / 32, 1024, 0, s>>>(dw_partial, dw, grid, H);
-        CM3P_LAUNCH_CHECK();
-    }
-    return CM3P_OK;
-}
-
-int cm3p_reduce_many(int njobs, const void* const* src, void* const* dst, const int64_t* n, const int* parts, const int* kind, void* stream) {
-    CM3P_REQUIRE(njobs >= 1 && njobs <= kReduceMaxJobs && src && dst && n && parts && kind);
-    ReduceJobs J{};
-    int blocks = 0;
-    for (int j = 0; j < njobs; ++j) {
-        CM3P_REQUIRE(src[j] && dst[j] && cm3p_aligned16(src[j]) && cm3p_aligned16(dst[j]) && n[j] > 0 && parts[j] >= 1 && (kind[j] == 0 || kind[j] == 1));
-        CM3P_REQUIRE(kind[j] == 1 ? n[j] <= 2048 : n[j] % 4 == 0);
-        J.src[j] = static_cast<const float*>(src[j]);
-        J.dst[j] = static_cast<float*>(dst[j]);
-        J.n[j] = n[j];
-        J.parts[j] = parts[j];
-        J.kind[j] = kind[j];
-        J.block0[j] = blocks;
-        // kind 0: one float4 per thread and trip, at most 512 workgroups per job (two per CU: the slabs stream at the HBM rate)
-        int64_t b = kind[j] == 1 ? (n[j] + 31) / 32 : (n[j] / 4 + 1023) / 1024;
-        if (kind[j] == 0 && b > 512) b = 512;
-        blocks += (int)b;
-    }
-    J.block0[njobs] = blocks;
-    J.njobs = njobs;
-    reduce_many_kernel<<<blocks, 1024, 0, static_cast<hipStream_t>(stream)>>>(J);
+    colsum_kernel<<<(H + 31) / 32, 1024, 0, s>>>(dw_partial, dw, grid, H);
     CM3P_LAUNCH_CHECK();
     return CM3P_OK;
 }

@@ -257,22 +257,19 @@ class _EncoderLayerFn(torch.autograd.Function):
         w_an, Wqkv_b, Wo_b, w_mn, Wi_b, Wo2_b = ctx.wb[:6]
         Wqkv_t, Wo_t, Wi_t, Wo2_t = ctx.wt
         ctx.saved = ctx.wb = ctx.wt = None  # release activations as we go
-        # the split-K combines of the four weight gradients and the column sums of the two norm-weight gradients: collected here,
-        # run as ONE launch at the end of this node (kernels.ReduceJobs) - nothing reads those gradients before this function returns
-        jobs = K.ReduceJobs()
         # ---- MLP branch: x_out = x_mid + g Wo2^T
         dg = K.linear_dgrad(gx16, Wo2_b, Wo2_t)
-        dWo2 = K.linear_wgrad(gx16, g, jobs) if n_o2 else None
+        dWo2 = K.linear_wgrad(gx16, g) if n_o2 else None
         dh = K.geglu_bwd(dg, h)
         del dg, g
         dxn2 = K.linear_dgrad(dh, Wi_b, Wi_t)
-        dWi = K.linear_wgrad(dh, xn2, jobs) if n_i else None
+        dWi = K.linear_wgrad(dh, xn2) if n_i else None
         del dh, h, xn2
-        gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True, jobs=jobs)
+        gx32, gx16, dw_mn = K.layernorm_bwd(dxn2, x_mid, w_mn, mean_m, rstd_m, gx32, True)
         del dxn2, x_mid
         # ---- attention branch: x_mid = x + o Wo^T
         do = K.linear_dgrad(gx16, Wo_b, Wo_t)
-        dWo = K.linear_wgrad(gx16, o, jobs) if n_o else None
+        dWo = K.linear_wgrad(gx16, o) if n_o else None
         # attention backward; the inverse rotary rotation of dq / dk is applied in its epilogue
         if geo.hd != 64:
             dqkv = K.attn_bwd_generic(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.hd, geo.windows[i], scale)
@@ -283,7 +280,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             dqkv = K.attn_bwd(qkv, o, do, lse, geo.key_mask, B, S, nh, geo.windows[i], scale, geo.rope[i], geo.per_batch_pos,
                               prescaled=True)
         del do, o, qkv
-        dWqkv = K.linear_wgrad(dqkv, xn, jobs) if n_qkv else None
+        dWqkv = K.linear_wgrad(dqkv, xn) if n_qkv else None
         if i == 0:
             dw_an = None
             if need[2]:
@@ -292,11 +289,10 @@ class _EncoderLayerFn(torch.autograd.Function):
             _hand_upstream(geo, gx32, None)
         elif need[2] or n_an:
             dxn = K.linear_dgrad(dqkv, Wqkv_b, Wqkv_t)
-            gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True, jobs=jobs)
+            gx32, gx16, dw_an = K.layernorm_bwd(dxn, x, w_an, mean_a, rstd_a, gx32, True)
             _hand_upstream(geo, gx32, gx16)
         else:  # everything below this layer is frozen: the chain ends here
             dw_an = None
-        jobs.run()  # (the gradients below are complete from here on)
         grads = [dWqkv, dWo, dw_mn, dWi, dWo2] if i == 0 else [dw_an, dWqkv, dWo, dw_mn, dWi, dWo2]
         out = [(gw if gw.dtype == dt else gw.to(dt)) if (nd and gw is not None) else None for gw, dt, nd in zip(grads, ctx.wdtypes, need[3:])]
         return (None, None, gx32 if need[2] else None, *out)

@@ -16,8 +16,7 @@ Tensor = torch.Tensor
 
 # C-ABI calls whose `work` is algorithmic BYTES (HBM-bound row-wise kernels); every other `work` is matmul FLOPs
 _lib.HBM_BOUND_TAGS.update({"cm3p_layernorm_fwd", "cm3p_layernorm_bwd", "cm3p_geglu_fwd", "cm3p_geglu_bwd", "attn_bwd_prep_kernel [global]",
-                            "attn_bwd_dq_reduce_kernel [global]", "attn_bwd_prep_kernel [global, varlen]", "attn_bwd_dq_reduce_kernel [global, varlen]",
-                            "cm3p_reduce_many"})
+                            "attn_bwd_dq_reduce_kernel [global]", "attn_bwd_prep_kernel [global, varlen]", "attn_bwd_dq_reduce_kernel [global, varlen]"})
 
 
 def _empty(shape, dtype, like: Tensor) -> Tensor:
@@ -38,56 +37,18 @@ def layernorm_fwd(x: Tensor, weight: Tensor, eps: float, want_f32: bool, want_bf
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, weight: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor],
-                  want_bf16: bool, inplace: bool = True, jobs: Optional["ReduceJobs"] = None):
-    """-> (dx_f32 = dres + LN'(dy), dx_bf16|None, dw[H]).  With `inplace` dx_f32 overwrites dres.
-    jobs: the column sum that finishes dw is left to `jobs.run()` (dw is valid only after it)."""
+                  want_bf16: bool, inplace: bool = True):
+    """-> (dx_f32 = dres + LN'(dy), dx_bf16|None, dw[H]).  With `inplace` dx_f32 overwrites dres."""
     rows, H = x.shape
     dx32 = dres if (inplace and dres is not None) else _empty((rows, H), torch.float32, x)
     dx16 = _empty((rows, H), torch.bfloat16, x) if want_bf16 else None
     nblk = query("cm3p_layernorm_bwd_blocks", rows)
     part = _empty((nblk, H), torch.float32, x)
     dw = _empty((H,), torch.float32, x)
-    defer = jobs is not None and jobs.enabled
     call("cm3p_layernorm_bwd", ptr(dy), dt(dy), ptr(x), ptr(weight, torch.float32), ptr(mean, torch.float32), ptr(rstd, torch.float32), ptr(dres), ptr(dx32), ptr(dx16),
-         ptr(part), None if defer else ptr(dw), rows, H, stream(),
+         ptr(part), ptr(dw), rows, H, stream(),
          work=float(rows) * H * (dy.element_size() + 4 + (4 if dres is not None else 0) + 4 + (2 if want_bf16 else 0)))
-    if defer:
-        jobs.add(part, dw, H, nblk, 1)
     return dx32, dx16, dw
-
-
-class ReduceJobs:
-    """The fixed-order reductions one backward node leaves behind - split-K slabs of its weight-gradient GEMMs, partial rows of its
-    LayerNorm weight gradients - collected while the node's kernels are issued and combined by ONE launch (`run()`, cm3p_reduce_many)
-    before the node returns its gradients.  Each was a launch of its own behind its producer until r05 (170 launches, 4.1 ms of a C4
-    step); the sums are taken in the same order, so the results are bit-identical.  CM3P_DEFER_REDUCE=0: the r05 behaviour (A/B)."""
-
-    MAX = 8  # (csrc/norm.hip: kReduceMaxJobs)
-
-    def __init__(self):
-        self.enabled = os.environ.get("CM3P_DEFER_REDUCE", "1") != "0"
-        self._jobs: list = []
-
-    def add(self, src: Tensor, dst: Tensor, n: int, parts: int, kind: int) -> None:
-        self._jobs.append((src, dst, int(n), int(parts), int(kind)))
-        if len(self._jobs) == self.MAX:
-            self.run()
-
-    def run(self) -> None:
-        jobs, self._jobs = self._jobs, []
-        if not jobs:
-            return
-        import ctypes
-
-        k = len(jobs)
-        src = (ctypes.c_void_p * k)(*[ptr(j[0], torch.float32) for j in jobs])
-        dst = (ctypes.c_void_p * k)(*[ptr(j[1], torch.float32) for j in jobs])
-        n = (ctypes.c_int64 * k)(*[j[2] for j in jobs])
-        parts = (ctypes.c_int * k)(*[j[3] for j in jobs])
-        kind = (ctypes.c_int * k)(*[j[4] for j in jobs])
-        anchor = ptr(jobs[0][0])  # (a device pointer among the arguments: call() launches on that tensor's GPU)
-        call("cm3p_reduce_many", k, src, dst, n, parts, kind, stream(), _anchor=anchor,
-             work=4.0 * sum(j[2] * (j[3] + 1) for j in jobs))
 
 
 def embed_ln_fwd(ids: Tensor, table: Tensor, weight: Tensor, eps: float, slot: Optional[Tensor] = None,
@@ -255,23 +216,11 @@ def linear_dgrad(dy: Tensor, w: Tensor, w_t: Optional[Tensor] = None) -> Tensor:
     return gemm(dy, w, T, K, N, True, False, EPI_BF16)
 
 
-def linear_wgrad(dy: Tensor, x: Tensor, jobs: Optional[ReduceJobs] = None) -> Tensor:
-    """dy [T,N] bf16, x [T,K] bf16 -> dW [N,K] fp32 = dy^T x (split-K over tokens, deterministic combine).
-    jobs: the GEMM leaves its split-K slabs in place and the combine is left to `jobs.run()` (dW is valid only after it)."""
+def linear_wgrad(dy: Tensor, x: Tensor) -> Tensor:
+    """dy [T,N] bf16, x [T,K] bf16 -> dW [N,K] fp32 = dy^T x (split-K over tokens, deterministic combine)."""
     T, N = dy.shape
     K = x.shape[1]
-    splits = _wgrad_splits(N, K, T)
-    if jobs is None or not jobs.enabled:
-        return gemm(dy, x, N, K, T, False, False, EPI_F32, split_k=splits)
-    slabs = query("cm3p_gemm_splitk_slabs", T, splits)
-    dW = _empty((N, K), torch.float32, dy)
-    # one slab: the GEMM writes dW itself and there is nothing to combine
-    ws = dW if slabs == 1 else _empty((slabs, N, K), torch.float32, dy)
-    call("cm3p_gemm_bf16_partials", ptr(dy), ptr(x), ptr(ws), N, K, T, dy.shape[1], x.shape[1], 0, 0, splits, stream(),
-         tag=_gemm_tag(N, K, T, False, False, EPI_F32, splits), work=2.0 * N * K * T)
-    if slabs > 1:
-        jobs.add(ws, dW, N * K, slabs, 0)
-    return dW
+    return gemm(dy, x, N, K, T, False, False, EPI_F32, split_k=_wgrad_splits(N, K, T))
 
 
 def cast_bf16(x: Tensor) -> Tensor:

@@ -31,7 +31,7 @@ extern "C" {
 #define CM3P_BF16 1
 
 /* ABI version of this header; cm3p_abi_version() must return it. */
-#define CM3P_ABI_VERSION 17
+#define CM3P_ABI_VERSION 16
 int cm3p_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -48,9 +48,7 @@ int cm3p_layernorm_bwd_blocks(int64_t rows);
 
 /* Backward of the above (autograd of the same nn.LayerNorm).  dx = dres + LN'(dy) where `dres` (may be NULL) is the
  * gradient already flowing on the residual stream: the pre-norm residual x + f(LN(x)) of
- * TF:...modeling_modernbert.py:331-332.  dx_f32 may alias dres.  dw[H] is fully overwritten.
- * dw == NULL (ABI 17): the column sum is left to the caller - dw_partial then holds cm3p_layernorm_bwd_blocks(rows) partial rows
- * [blocks, H] that cm3p_reduce_many (kind 1) sums later, together with the other reductions of the same encoder layer. */
+ * TF:...modeling_modernbert.py:331-332.  dx_f32 may alias dres.  dw[H] is fully overwritten. */
 int cm3p_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* weight, const float* mean,
                        const float* rstd, const float* dres, float* dx_f32, void* dx_bf16, float* dw_partial, float* dw,
                        int64_t rows, int H, void* stream);
@@ -159,26 +157,6 @@ int cm3p_qkv_gemm_rope(const void* x, const void* Wqkv, void* qkv, int64_t M, in
 
 /* Host-only: the split_k the library recommends for a weight-gradient GEMM of this shape (sizes the workspace). */
 int cm3p_gemm_wgrad_splits(int64_t M, int64_t N, int64_t K);
-
-/* The weight-gradient GEMM without its combine pass (ABI 17): C = sum over slabs of workspace[z][M][N] (fp32), z < cm3p_gemm_splitk_slabs(K,
- * split_k) - the number of k-ranges the library really cuts for this K (ranges are multiples of 128 / 64, so it may be below split_k;
- * host-only query).  Same kernels, grid and slab contents as cm3p_gemm_bf16 with CM3P_EPI_F32 and this split_k; what is left out is the
- * splitk_reduce launch behind it.  The caller sums the slabs with cm3p_reduce_many (kind 0), normally once per encoder layer for all of
- * the layer's weight gradients and LayerNorm weight gradients (autograd of the nn.Linear / nn.LayerNorm members of
- * TF:models/modernbert/modeling_modernbert.py:318-333: none of those gradients is read before the layer's backward returns).
- * split_k == 1 writes the single slab workspace[0] = C. */
-int cm3p_gemm_splitk_slabs(int64_t K, int split_k);
-int cm3p_gemm_bf16_partials(const void* A, const void* B, float* workspace, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                            int a_kc, int b_kc, int split_k, void* stream);
-
-/* Up to 8 fixed-order reductions in ONE launch.  All five arrays are HOST arrays of njobs entries (copied into the kernel's arguments;
- * no device table, no allocation).  Job j:
- *   kind[j] == 0: dst[j][i] = sum_{z < parts[j]} src[j][z * n[j] + i], i < n[j] (n[j] % 4 == 0), slabs added in ascending z - the
- *                 combine pass of cm3p_gemm_bf16's split-K, bit-identical to it;
- *   kind[j] == 1: dst[j][c] = sum_{b < parts[j]} src[j][b * n[j] + c], c < n[j] <= 2048 - the column sum behind cm3p_layernorm_bwd
- *                 (same slice order, bit-identical to it).
- * src / dst are device pointers, 16-byte aligned; a dst may not alias any src. */
-int cm3p_reduce_many(int njobs, const void* const* src, void* const* dst, const int64_t* n, const int* parts, const int* kind, void* stream);
 
 /* fp32 -> bf16 cast of n elements (n % 4 == 0): the autocast weight / activation cast in front of a bf16 linear. */
 int cm3p_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);

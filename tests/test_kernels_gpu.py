@@ -978,74 +978,3 @@ def test_wi_gemm_with_geglu_in_its_store_phase_equals_the_two_kernels(K, T, I, K
     got = K.gemm_geglu(x, w.index_select(0, K.geglu_interleave_index(I, w.device)).contiguous())
     assert torch.equal(got, want)
 
-
-
-# ---- deferred reductions (r06: cm3p_gemm_bf16_partials / cm3p_layernorm_bwd with dw == NULL / cm3p_reduce_many) ----------------------------
-@pytest.mark.parametrize("T,N,K_", [(16384, 768, 2304), (32768, 776, 264), (4096, 768, 384), (777, 72, 96), (131072, 256, 256)])
-def test_deferred_wgrad_combine_is_bit_identical_to_the_immediate_one(K, monkeypatch, T, N, K_):
-    """dW through cm3p_gemm_bf16_partials + one cm3p_reduce_many against cm3p_gemm_bf16's own split-K combine: the same slabs summed in
-    the same order, so random data must agree to the last bit; integer data must be exact."""
-    g = torch.Generator().manual_seed(T + N)
-    dy = _bf(torch.randn(T, N, generator=g)).to(DEV)
-    x = _bf(torch.randn(T, K_, generator=g)).to(DEV)
-    want = K.linear_wgrad(dy, x)
-    jobs = K.ReduceJobs()
-    assert jobs.enabled
-    got = K.linear_wgrad(dy, x, jobs)
-    jobs.run()
-    assert torch.equal(got, want)
-    dyi = _bf(torch.randint(-2, 3, (T, N), generator=g).float())
-    xi = _bf(torch.randint(-2, 3, (T, K_), generator=g).float())
-    jobs = K.ReduceJobs()
-    goti = K.linear_wgrad(dyi.to(DEV), xi.to(DEV), jobs)
-    jobs.run()
-    _assert_close(goti, dyi.float().t() @ xi.float(), 0, 0, "deferred wgrad")
-    monkeypatch.setenv("CM3P_DEFER_REDUCE", "0")
-    assert not K.ReduceJobs().enabled
-
-
-def test_six_reductions_of_a_layer_in_one_launch_equal_their_own_kernels(K):
-    """What _EncoderLayerFn.backward collects - four weight gradients (different slab counts) and two LayerNorm weight gradients - run as
-    ONE cm3p_reduce_many launch, against the r05 path (every reduction behind its producer): bit-identical, dx of the norms included."""
-    T, H, I = 8192, 768, 1152
-    g = torch.Generator().manual_seed(3)
-    mk = lambda *s: _bf(torch.randn(*s, generator=g)).to(DEV)
-    pairs = [(mk(T, H), mk(T, I)), (mk(T, 2 * I), mk(T, H)), (mk(T, H), mk(T, H)), (mk(T, 3 * H), mk(T, H))]
-    x = torch.randn(T, H, generator=g).to(DEV)
-    w = torch.randn(H, generator=g).to(DEV)
-    _, _, mean, rstd = K.layernorm_fwd(x, w, 1e-5, False, True)
-    dys = [mk(T, H), mk(T, H)]
-    res = torch.randn(T, H, generator=g).to(DEV)
-    want_w = [K.linear_wgrad(a, b) for a, b in pairs]
-    want_n = [K.layernorm_bwd(dy, x, w, mean, rstd, res.clone(), True) for dy in dys]
-    jobs = K.ReduceJobs()
-    got_w = [K.linear_wgrad(a, b, jobs) for a, b in pairs]
-    got_n = [K.layernorm_bwd(dy, x, w, mean, rstd, res.clone(), True, jobs=jobs) for dy in dys]
-    assert len(jobs._jobs) == 6
-    jobs.run()
-    assert not jobs._jobs
-    for a, b in zip(got_w, want_w):
-        assert torch.equal(a, b)
-    for a, b in zip(got_n, want_n):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    # more than eight jobs: the collector runs a full batch by itself
-    jobs = K.ReduceJobs()
-    many = [K.linear_wgrad(pairs[0][0], pairs[0][1], jobs) for _ in range(9)]
-    jobs.run()
-    assert all(torch.equal(m, want_w[0]) for m in many)
-
-
-def test_reduce_many_rejects_bad_arguments(K):
-    import ctypes
-
-    from cm3p_amd import _lib
-
-    lib = _lib.load()
-    a = torch.zeros(8, device=DEV)
-    P, L, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
-    one = lambda t, v: (t * 1)(v)
-    ok = (one(P, a.data_ptr()), one(P, a.data_ptr()), one(L, 4), one(I, 1), one(I, 0))
-    assert lib.cm3p_reduce_many(0, *ok, None) != 0 and lib.cm3p_reduce_many(9, *ok, None) != 0  # job count out of range
-    assert lib.cm3p_reduce_many(1, ok[0], ok[1], one(L, 6), ok[3], ok[4], None) != 0  # kind 0: n % 4
-    assert lib.cm3p_reduce_many(1, ok[0], ok[1], one(L, 4096), ok[3], one(I, 1), None) != 0  # kind 1: more than 2048 columns
-    assert lib.cm3p_reduce_many(1, ok[0], ok[1], ok[2], ok[3], one(I, 2), None) != 0  # unknown kind

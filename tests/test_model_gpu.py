@@ -211,30 +211,6 @@ def test_metadata_tower_on_its_own_stream_gives_the_same_step(monkeypatch):
         assert torch.equal(res["0"][1][k], res["1"][1][k]), k
 
 
-def test_one_reduction_launch_per_layer_gives_the_same_step_and_no_separate_reduction_kernels(monkeypatch):
-    """r06: a layer's split-K combines and LayerNorm column sums run as ONE cm3p_reduce_many launch at the end of its backward
-    (kernels.ReduceJobs); CM3P_DEFER_REDUCE=0 is the r05 path with each reduction behind its producer.  Same loss, same gradients to the
-    last bit (every sum keeps its order); and with the deferral on, a step issues one reduction launch per encoder layer."""
-    from cm3p_amd import _lib
-
-    name = "d64_mean_pad"
-    blob = load_file(os.path.join(GOLD, f"{name}.safetensors"))
-    res, launches = {}, {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CM3P_DEFER_REDUCE", mode)
-        model = _build(name)
-        out = model(**_inputs(blob))
-        _lib.profile_begin()
-        out.loss.backward()
-        launches[mode] = _lib.profile_end()
-        res[mode] = (out.loss.detach().clone(), {k: p_.grad.clone() for k, p_ in model.named_parameters() if p_.grad is not None})
-    assert torch.equal(res["0"][0], res["1"][0]) and res["0"][1].keys() == res["1"][1].keys()
-    for k in res["0"][1]:
-        assert torch.equal(res["0"][1][k], res["1"][1][k]), k
-    n_layers = sum(len(t.encoder.layers) for t in (model.beatmap_model, model.metadata_model))
-    assert "cm3p_reduce_many" not in launches["0"] and launches["1"]["cm3p_reduce_many"][0] == n_layers
-
-
 def test_forward_only_calls_fuse_geglu_into_the_wi_gemm_without_changing_a_bit(monkeypatch):
     """Default config, 8 x 4096 beatmap tokens under no_grad: the beatmap tower's Wi GEMMs take the fused kernel
     (encoder._EncoderLayerFn.forward, kernels.gemm_geglu); CM3P_GEGLU_FUSED=0 keeps GEMM + geglu_fwd.  Same embeddings to the bit;
