@@ -50,7 +50,9 @@ namespace {
 #define CM3P_FABL 0  // timing-only ablation builds (tools/ubench/attn_bwd_ablate.sh; results are wrong by construction): 1 no barrier,
 #endif               // 2 no tile DMA in the loop, 4 no dS image writes, 8 no dQ operand reads, 16 no slab stores, 32 no dQ MFMAs,
                      // 64 no exponentials, 128 no dS multiplies, 256 no bf16 packs (P / dS fragments a non-zero constant), 512 no Q / dO
-                     // row-fragment and statistics reloads, 1024 no transposed Q^T / dO^T fragment reloads
+                     // row-fragment and statistics reloads, 1024 no transposed Q^T / dO^T fragment reloads, 2048 the twelve accumulating
+                     // products of a step (dV^T, dK^T, dQ^T) as pairs of v_mfma_f32_16x16x32_bf16 on four-register accumulators: the same
+                     // FLOPs in the other MFMA shape with none of the layout work a port needs (r06, tools/ubench/attn_mfma_shape.sh)
 
 // Wait trace (-DCM3P_FTRACE=1, tools/attn_bwd_trace.py): per wave the cycles spent (0) at the counted vmcnt wait - the DMA of tile t+1 not landed -,
 // (1) at the LDS drain + the tile's one barrier, and (2) in all; the stamps are read behind the barrier's own lgkmcnt(0), so they add no wait.
@@ -85,6 +87,21 @@ __device__ __forceinline__ void mfma_ava(f32x16& d, const bf16x8& a, const bf16x
 }
 __device__ __forceinline__ void mfma_vva(f32x16& d, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+// ---- timing-only forms of the accumulating products (CM3P_FABL & 2048): two 16x16x32 MFMAs on two quads where the product issues one
+// 32x32x16 on a 16-register block.  The accumulators are DECLARED as quads in that build (carving quads out of a 16-register tuple per
+// MFMA makes hipcc copy the tuple around every statement: thousands of v_accvgpr_* and scratch).
+constexpr bool kQuads = (CM3P_FABL & 2048) != 0;
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void mfma16_av0(f32x4& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_ava(f32x4& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_vva(f32x4& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
 // workgroup barrier that orders LDS traffic only (this wave's LDS-DMA is covered by the counted vmcnt wait in front of it)
@@ -313,12 +330,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         }
     }
     f32x16 dk[2][2], dv[2][2];  // [d block][key block]
+    f32x4 dkq[kQuads ? 2 : 1][2][2], dvq[kQuads ? 2 : 1][2][2];  // (timing build only: [d block][key block][quad])
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (kQuads) {
+                dkq[db][kb][0] = dkq[db][kb][1] = dvq[db][kb][0] = dvq[db][kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;
+                for (int i = 0; i < 16; ++i) dk[db][kb][i] = dv[db][kb][i] = 0.f;
+            }
+        }
+#define CM3P_GRAD_MFMA(acc, accq, DB, KB, A, B)                              \
+    do {                                                                     \
+        if constexpr (kQuads) {                                              \
+            accq[DB][KB][0] = mfma16(A, B, accq[DB][KB][0]);                 \
+            accq[DB][KB][1] = mfma16(A, B, accq[DB][KB][1]);                 \
+        } else {                                                             \
+            acc[DB][KB] = mfma32(A, B, acc[DB][KB]);                         \
+        }                                                                    \
+    } while (0)
 
     // ---- per-lane LDS byte offsets; everything else is an immediate
     int oR[4], oTlo[2], oThi[2];
@@ -361,6 +393,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     bf16x8 ktA[NKA];            // K^T operands of k-steps 0 .. NKA-1 of the dQ product (AGPRs: 192 + 60 of the 256)
     bf16x8 ktV[2];              // ... and of the last k-steps, re-read from the K image every tile
     f32x16 dq;                  // dQ^T block of the current epoch
+    f32x4 dqq[2];               // (timing build only: its two quads)
     uint4 zr0, zr1;             // the finished epoch's block, row-major: 16 bytes of rows lane >> 2 and 16 + (lane >> 2)
     auto load_init = [&](const char* sq, f32x16& v, int which, int half) {
 #pragma unroll
@@ -396,6 +429,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
     auto dq_mfma = [&](auto ks_c, auto first_c, const bf16x8& bq) {
         constexpr int KS = decltype(ks_c)::value;
         if constexpr ((CM3P_FABL & 32) != 0) return;
+        if constexpr (kQuads) {
+            if constexpr (decltype(first_c)::value != 0) {
+                mfma16_av0(dqq[0], ktA[KS], bq);
+                mfma16_av0(dqq[1], ktA[KS], bq);
+            } else if constexpr (KS >= NKA) {
+                mfma16_vva(dqq[0], ktV[KS & 1], bq);
+                mfma16_vva(dqq[1], ktV[KS & 1], bq);
+            } else {
+                mfma16_ava(dqq[0], ktA[KS], bq);
+                mfma16_ava(dqq[1], ktA[KS], bq);
+            }
+            return;
+        }
         if constexpr (decltype(first_c)::value != 0) mfma_av0(dq, ktA[KS], bq);
         else if constexpr (KS >= NKA) mfma_vva(dq, ktV[KS & 1], bq);
         else mfma_ava(dq, ktA[KS], bq);
@@ -485,21 +531,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         CM3P_SB();
         // ---- gradient products of X: dV^T += dO^T P, dK^T += Q^T dS; dS -> image
         const bf16x8 pf0 = to_frag(Xs, 0);
-        dv[0][KBX] = mfma32(gT[0][0], pf0, dv[0][KBX]);
+        CM3P_GRAD_MFMA(dv, dvq, 0, KBX, gT[0][0], pf0);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < ((CM3P_FABL & 128) ? 0 : 4); ++i) Xdp[i] *= Xs[i];
         load_dq_operand(dqB1, RBUF, KS0 + 3);
         CM3P_HOOK(8);
         CM3P_SB();
-        dv[1][KBX] = mfma32(gT[0][1], pf0, dv[1][KBX]);
+        CM3P_GRAD_MFMA(dv, dvq, 1, KBX, gT[0][1], pf0);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 1, 0);
 #pragma unroll
         for (int i = 4; i < ((CM3P_FABL & 128) ? 0 : 8); ++i) Xdp[i] *= Xs[i];
         const bf16x8 ds0 = to_frag(Xdp, 0);
         CM3P_HOOK(9);
         CM3P_SB();
-        dk[0][KBX] = mfma32(qT[0][0], ds0, dk[0][KBX]);
+        CM3P_GRAD_MFMA(dk, dkq, 0, KBX, qT[0][0], ds0);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 0, 1);
         const bf16x8 pf1 = to_frag(Xs, 1);
         if constexpr ((CM3P_FABL & 4) == 0) {
@@ -509,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         }
         CM3P_HOOK(10);
         CM3P_SB();
-        dk[1][KBX] = mfma32(qT[0][1], ds0, dk[1][KBX]);
+        CM3P_GRAD_MFMA(dk, dkq, 1, KBX, qT[0][1], ds0);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 0, 1, 1);
 #pragma unroll
         for (int i = 8; i < ((CM3P_FABL & 128) ? 0 : 12); ++i) Xdp[i] *= Xs[i];
@@ -518,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         dq_mfma(std::integral_constant<int, KS0 + 2>{}, std::integral_constant<int, 0>{}, dqB0);
         CM3P_HOOK(18);
         CM3P_SB();
-        dv[0][KBX] = mfma32(gT[1][0], pf1, dv[0][KBX]);
+        CM3P_GRAD_MFMA(dv, dvq, 0, KBX, gT[1][0], pf1);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 0, 0);
 #pragma unroll
         for (int i = 12; i < ((CM3P_FABL & 128) ? 0 : 16); ++i) Xdp[i] *= Xs[i];
@@ -526,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         if constexpr (NKS0 >= 0) load_dq_operand(dqB0, NRBUF, NKS0);
         CM3P_HOOK(12);
         CM3P_SB();
-        dv[1][KBX] = mfma32(gT[1][1], pf1, dv[1][KBX]);
+        CM3P_GRAD_MFMA(dv, dvq, 1, KBX, gT[1][1], pf1);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 1, 0);
         if constexpr ((CM3P_FABL & 4) == 0) {
             const uint4 w = __builtin_bit_cast(uint4, ds1);
@@ -535,11 +581,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         }
         CM3P_HOOK(13);
         CM3P_SB();
-        dk[0][KBX] = mfma32(qT[1][0], ds1, dk[0][KBX]);
+        CM3P_GRAD_MFMA(dk, dkq, 0, KBX, qT[1][0], ds1);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 0, 1);
         CM3P_HOOK(14);
         CM3P_SB();
-        dk[1][KBX] = mfma32(qT[1][1], ds1, dk[1][KBX]);
+        CM3P_GRAD_MFMA(dk, dkq, 1, KBX, qT[1][1], ds1);
         if constexpr (KBX == 1 && (CM3P_FABL & 1024) == 0) loadG_one(nG, 1, 1, 1);
         CM3P_HOOK(15);
         CM3P_SB();
@@ -599,9 +645,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
             if constexpr (C == 1 && (CM3P_FABL & 2) == 0) dma_stat(SL);
             if constexpr (C == 2 || C == 3) {
 #pragma unroll
-                for (int g = 2 * (C - 2); g < 2 * (C - 2) + 2; ++g)
-                    *reinterpret_cast<uint2*>(smem + zW + 16 * g) =
-                        uint2{pack_bf16x2(dq[4 * g], dq[4 * g + 1]), pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3])};
+                for (int g = 2 * (C - 2); g < 2 * (C - 2) + 2; ++g) {
+                    if constexpr (kQuads)
+                        *reinterpret_cast<uint2*>(smem + zW + 16 * g) =
+                            uint2{pack_bf16x2(dqq[g & 1][0], dqq[g & 1][1]), pack_bf16x2(dqq[g & 1][2], dqq[g & 1][3])};
+                    else
+                        *reinterpret_cast<uint2*>(smem + zW + 16 * g) =
+                            uint2{pack_bf16x2(dq[4 * g], dq[4 * g + 1]), pack_bf16x2(dq[4 * g + 2], dq[4 * g + 3])};
+                }
             }
             if constexpr (C == 6) {
                 asm volatile("" ::: "memory");  // (the uint2 stores above and these uint4 loads do not alias by type: keep their order)
@@ -694,8 +745,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
         mfma_va(dpA, Gf[s4], vf[0][s4]);
     }
     // (epoch -1 does not exist: the dQ product of tile 0's first two steps runs on whatever the image holds and goes to the dump rows)
+    if constexpr (kQuads) {
+        dqq[0] = dqq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+        for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+    }
     load_dq_operand(dqB0, 1, 8);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the only place a result is read right behind its asm MFMA chain)
     CM3P_SB();
@@ -727,6 +782,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const uint16_t* 
 
 
     // ---- epilogue: dK = scale * dK^T acc (inverse rotary applied), dV; keys under the padding mask get zeros
+    if constexpr (kQuads) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    dk[db][kb][i] = dkq[db][kb][(i >> 2) & 1][i & 3];
+                    dv[db][kb][i] = dvq[db][kb][(i >> 2) & 1][i & 3];
+                }
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         const int krow = k0 + 32 * kb + l31;

@@ -37,7 +37,8 @@ namespace {
 
 #ifndef CM3P_GABL
 #define CM3P_GABL 0  // timing-only ablation builds (results wrong by construction): 1 no exponentials, 2 no max, 4 no row sums, 8 no tile DMA in the loop, 16 no barrier, 32 max and decision kept but no branch,
-                    // 64 no K / V fragment reloads in the loop, 128 no bf16 packs, 256 the score products start from the constant 0
+                    // 64 no K / V fragment reloads in the loop, 128 no bf16 packs, 256 the score products start from the constant 0,
+                    // 512 the output product as pairs of v_mfma_f32_16x16x32_bf16 (same FLOPs; tools/ubench/attn_mfma_shape.sh)
 #endif
 
 // Cycle trace (trace builds only: -DCM3P_GTRACE=1, tools/attn_fwd_trace.py): every wave accumulates, in scalar registers, the shader cycles
@@ -94,6 +95,19 @@ __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8&
 __device__ __forceinline__ void mfma_o(f32x16& d, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
 }
+// Timing only (CM3P_GABL & 512; r06, the shape question of the r05 verdict): the output product's FLOPs as TWO v_mfma_f32_16x16x32_bf16
+// on two four-register accumulators - what it would issue in that shape, with none of the layout work a port needs (results wrong by
+// construction).  The accumulators are declared as quads in that build: carving four registers out of a 16-register tuple per MFMA made
+// hipcc copy the tuple around every statement (6874 v_accvgpr_* and scratch in the first try).
+__device__ __forceinline__ void mfma_o4(f32x4& lo, f32x4& hi, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %3, %1" : "+a"(lo), "+a"(hi) : "v"(a), "v"(b));
+}
+constexpr bool kOQuads = (CM3P_GABL & 512) != 0;
+#define CM3P_MFMA_O(u, db, a, b)                                                  \
+    do {                                                                          \
+        if constexpr (kOQuads) mfma_o4(oq[u][db][0], oq[u][db][1], a, b);         \
+        else mfma_o(oacc[u][db], a, b);                                           \
+    } while (0)
 // Pins a value where it is computed.  The cold blocks (mask, reference move) split a period into several basic blocks, and hipcc's
 // sinking pass moves pure VALU work across sched_barriers into the block of its first use - the exponentials of a sub-block ended
 // up in front of the PV MFMAs of the NEXT period, all 16 of a chunk pair in a row.  A volatile asm statement cannot be crossed.
@@ -224,12 +238,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     // reference point in log2 units that every p, l and O is relative to, negref its negative splat over the 16 registers of an
     // MFMA C operand, thr the amount a tile maximum may exceed it before it is moved (-inf until the row has seen a visible key:
     // the first one sets the reference exactly), lA / lB two partial row sums.
-    f32x16 oacc[U][2], negref[U];
+    f32x16 oacc[kOQuads ? 1 : U][2], negref[U];  // (the timing build keeps its accumulators in oq and never touches oacc in the sweep)
+    f32x4 oq[kOQuads ? U : 1][2][2];  // (timing build only: CM3P_MFMA_O)
     float lA[U], lB[U], ref[U], thr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+        if constexpr (kOQuads) oq[u][0][0] = oq[u][0][1] = oq[u][1][0] = oq[u][1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[u][0][i] = oacc[u][1][i] = negref[u][i] = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            negref[u][i] = 0.f;
+            if constexpr (!kOQuads) oacc[u][0][i] = oacc[u][1][i] = 0.f;
+        }
         lA[u] = lB[u] = ref[u] = 0.f;
         thr[u] = kNegInf;
     }
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         float ma, mb;
         // gap 0
         CM3P_SB();
-        mfma_o(oacc[UP][0], Vf[0][0], __builtin_bit_cast(bf16x8, Pw[0]));
+        CM3P_MFMA_O(UP, 0, Vf[0][0], __builtin_bit_cast(bf16x8, Pw[0]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(0), CM3P_IC(0));
         A(So, 3, 6, lA[UP]);  // tail of the sub-block before: its last chunk's row sums fill the light gaps 0-3
         A(So, 3, 7, lB[UP]);
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         GT2(0);
         // gap 1
         CM3P_SB();
-        mfma_o(oacc[UP][1], Vf[0][1], __builtin_bit_cast(bf16x8, Pw[0]));
+        CM3P_MFMA_O(UP, 1, Vf[0][1], __builtin_bit_cast(bf16x8, Pw[0]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(0), CM3P_IC(1));
         A(So, 3, 0, lA[UP]);
         A(So, 3, 1, lB[UP]);
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         GT2(1);
         // gap 2
         CM3P_SB();
-        mfma_o(oacc[UP][0], Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
+        CM3P_MFMA_O(UP, 0, Vf[1][0], __builtin_bit_cast(bf16x8, Pw[1]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(1), CM3P_IC(0));
         if constexpr ((CM3P_GABL & 2) == 0) {
             mb = vmax3(mb, Sc[1][4], Sc[1][5]);
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         // gap 3: the last of the maximum, the wave-uniform decision, THEN four row-sum adds, then the branch: a branch right behind the
         // compare that feeds it waits out the VALU -> scalar round trip with nothing to issue
         CM3P_SB();
-        mfma_o(oacc[UP][1], Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
+        CM3P_MFMA_O(UP, 1, Vf[1][1], __builtin_bit_cast(bf16x8, Pw[1]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(1), CM3P_IC(1));
         if constexpr ((CM3P_GABL & 2) == 0) {
             ma = vmax3(ma, Sc[1][14], Sc[1][15]);
@@ -405,13 +424,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
                 const float nr = -ref[UU];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float o0 = oacc[UU][0][i], o1 = oacc[UU][1][i], nv = negref[UU][i], tmp;
+                    if constexpr (kOQuads) {  // (timing build: the rare block only rewrites the -ref splat)
+                        negref[UU][i] = nr;
+                        continue;
+                    }
+                    constexpr int UO = kOQuads ? 0 : UU;
+                    float o0 = oacc[UO][0][i], o1 = oacc[UO][1][i], nv = negref[UU][i], tmp;
                     asm volatile("v_accvgpr_read_b32 %3, %0\n\tv_mov_b32 %2, %5\n\tv_mul_f32 %3, %3, %4\n\tv_accvgpr_write_b32 %0, %3\n\t"
                                  "v_accvgpr_read_b32 %3, %1\n\ts_nop 0\n\tv_mul_f32 %3, %3, %4\n\tv_accvgpr_write_b32 %1, %3"
                                  : "+a"(o0), "+a"(o1), "=&v"(nv), "=&v"(tmp)
                                  : "v"(alpha), "v"(nr));
-                    oacc[UU][0][i] = o0;
-                    oacc[UU][1][i] = o1;
+                    oacc[UO][0][i] = o0;
+                    oacc[UO][1][i] = o1;
                     negref[UU][i] = nv;
                 }
             }
@@ -425,24 +449,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         GT2(4);
         // gaps 4-6: chunk 0
         CM3P_SB();
-        mfma_o(oacc[UP][0], Vf[2][0], __builtin_bit_cast(bf16x8, Pw[2]));
+        CM3P_MFMA_O(UP, 0, Vf[2][0], __builtin_bit_cast(bf16x8, Pw[2]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(2), CM3P_IC(0));
         E(Sc, 0, 0); E(Sc, 0, 1); E(Sc, 0, 2);
         CM3P_SB();
-        mfma_o(oacc[UP][1], Vf[2][1], __builtin_bit_cast(bf16x8, Pw[2]));
+        CM3P_MFMA_O(UP, 1, Vf[2][1], __builtin_bit_cast(bf16x8, Pw[2]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(2), CM3P_IC(1));
         E(Sc, 0, 3); E(Sc, 0, 4); E(Sc, 0, 5);
         A(Sc, 0, 0, lA[UU]); A(Sc, 0, 1, lB[UU]); A(Sc, 0, 2, lA[UU]);
         if constexpr (UU == (U == 2 ? 0 : 1)) dma_k(t + 3);
         CM3P_SB();
-        mfma_o(oacc[UP][0], Vf[3][0], __builtin_bit_cast(bf16x8, Pw[3]));
+        CM3P_MFMA_O(UP, 0, Vf[3][0], __builtin_bit_cast(bf16x8, Pw[3]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(3), CM3P_IC(0));
         E(Sc, 0, 6); E(Sc, 0, 7);
         A(Sc, 0, 3, lB[UU]); A(Sc, 0, 4, lA[UU]); A(Sc, 0, 5, lB[UU]);
         C2(Sc, 0, 0);
         // gaps 7-9: chunk 1 (gap 7 is the last PV MFMA: Pw[3] of the sub-block before is free from here on)
         CM3P_SB();
-        mfma_o(oacc[UP][1], Vf[3][1], __builtin_bit_cast(bf16x8, Pw[3]));
+        CM3P_MFMA_O(UP, 1, Vf[3][1], __builtin_bit_cast(bf16x8, Pw[3]));
         if constexpr (RV && (CM3P_GABL & 64) == 0) load_v(stV, CM3P_IC(3), CM3P_IC(1));
         E(Sc, 1, 0); E(Sc, 1, 1); E(Sc, 1, 2);
         A(Sc, 0, 6, lA[UU]); A(Sc, 0, 7, lB[UU]);
@@ -568,8 +592,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
     A(SB, 3, 5, lB[U - 1]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        mfma_o(oacc[U - 1][0], Vf[s][0], __builtin_bit_cast(bf16x8, Pw[s]));
-        mfma_o(oacc[U - 1][1], Vf[s][1], __builtin_bit_cast(bf16x8, Pw[s]));
+        CM3P_MFMA_O(U - 1, 0, Vf[s][0], __builtin_bit_cast(bf16x8, Pw[s]));
+        CM3P_MFMA_O(U - 1, 1, Vf[s][1], __builtin_bit_cast(bf16x8, Pw[s]));
     }
     // no DMA may be in flight when the ring becomes the transposition buffers (or when the workgroup's LDS is handed on)
     dma_wait_barrier(0);
@@ -580,8 +604,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_g_kernel(const uint16_t* __re
         const float l_tot = lh + __shfl_xor(lh, 32, 64);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         const int qrow = q0 + 32 * u + l31;
-        store_rows32(smem + 4608 * wid, oacc[u][0], oacc[u][1], inv, out + (sv.row0 + q0 + 32 * u) * nh * 64 + head * 64, (int64_t)nh * 64,
-                     S - (q0 + 32 * u), lane);
+        if constexpr (kOQuads) {
+            f32x16 t0, t1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                t0[i] = oq[u][0][(i >> 2) & 1][i & 3];
+                t1[i] = oq[u][1][(i >> 2) & 1][i & 3];
+            }
+            store_rows32(smem + 4608 * wid, t0, t1, inv, out + (sv.row0 + q0 + 32 * u) * nh * 64 + head * 64, (int64_t)nh * 64, S - (q0 + 32 * u), lane);
+        } else {
+            store_rows32(smem + 4608 * wid, oacc[kOQuads ? 0 : u][0], oacc[kOQuads ? 0 : u][1], inv, out + (sv.row0 + q0 + 32 * u) * nh * 64 + head * 64,
+                         (int64_t)nh * 64, S - (q0 + 32 * u), lane);
+        }
         if (qrow < S && hh == 0)
             lse[sv.stat0 + qrow] = l_tot > 0.f ? (ref[u] + __log2f(l_tot)) * 0.69314718055994531f : __builtin_huge_valf();
     }
