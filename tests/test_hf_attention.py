@@ -115,6 +115,86 @@ def test_third_party_modernbert_through_the_seam_sees_the_reference_masks(monkey
 
 
 # ---- the kernels behind the seam (`-m gpu`) --------------------------------------------------------------------------------------------
+def _odd_masks(S, B):
+    """left padding, a hole in the middle, every second key invisible, a single visible key: the kernels take ANY key mask"""
+    m = torch.ones(B, S, dtype=torch.long)
+    m[0, : S // 3] = 0
+    m[1, S // 4: S // 2] = 0
+    if B > 2:
+        m[2, ::2] = 0
+    if B > 3:
+        m[3] = 0
+        m[3, S // 2] = 1
+    return m
+
+
+def test_arbitrary_key_masks_pass_through_the_seam_unchanged(monkeypatch):
+    """Left padding, holes, alternating keys, one visible key: the mask function hands the 2-D mask over as bytes and the dense rule on the
+    other side of the seam reproduces `sdpa` on every VISIBLE position (a hidden query row is garbage on both sides, as in the reference)."""
+    import cm3p_amd.hf_attention as H
+    from transformers import ModernBertModel
+
+    monkeypatch.setattr(H, "_run", dense_rule)
+    torch.manual_seed(2)
+    ref = ModernBertModel._from_config(_tiny_config(), attn_implementation="sdpa").eval()
+    hip = ModernBertModel._from_config(_tiny_config(), attn_implementation=H.NAME).eval()
+    hip.load_state_dict(ref.state_dict())
+    S, B = 160, 4
+    mask = _odd_masks(S, B)
+    ids = torch.randint(3, 97, (B, S)) * mask
+    with torch.no_grad():
+        want = ref(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = hip(input_ids=ids, attention_mask=mask).last_hidden_state
+    v = mask.bool()
+    assert torch.isfinite(got).all() and (got[v] - want[v]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_hf_attention_seam_with_left_padding_and_holes_on_the_hip_kernels():
+    import cm3p_amd.hf_attention as H
+    from transformers import ModernBertModel
+
+    torch.manual_seed(2)
+    ref = ModernBertModel._from_config(_tiny_config(), attn_implementation="sdpa").eval()
+    hip = ModernBertModel._from_config(_tiny_config(), attn_implementation=H.NAME).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to("cuda")
+    S, B = 160, 4
+    mask = _odd_masks(S, B)
+    ids = torch.randint(3, 97, (B, S)) * mask
+    with torch.no_grad():
+        want = ref(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = hip(input_ids=ids.cuda(), attention_mask=mask.cuda()).last_hidden_state.float().cpu()
+    v = mask.bool()
+    assert torch.isfinite(got).all()
+    rel = ((got[v] - want[v]).norm() / want[v].norm()).item()
+    assert 0 < rel <= 2e-2, rel
+
+
+@pytest.mark.gpu
+def test_hf_attention_seam_head_dim_32_takes_the_generic_kernels():
+    """hidden 64 / 2 heads = head_dim 32: the seam routes to csrc/attention_generic.hip (fp32 kernels), same visibility rule."""
+    import cm3p_amd.hf_attention as H
+    from transformers import ModernBertModel
+
+    torch.manual_seed(3)
+    cfg = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2)
+    ref = ModernBertModel._from_config(_tiny_config(**cfg), attn_implementation="sdpa").eval()
+    hip = ModernBertModel._from_config(_tiny_config(**cfg), attn_implementation=H.NAME).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to("cuda")
+    S, lens = 150, (150, 90, 33)
+    ids = torch.randint(3, 97, (len(lens), S))
+    mask = (torch.arange(S)[None, :] < torch.tensor(lens)[:, None]).long()
+    ids = ids * mask
+    with torch.no_grad():
+        want = ref(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = hip(input_ids=ids.cuda(), attention_mask=mask.cuda()).last_hidden_state.float().cpu()
+    v = mask.bool()
+    rel = ((got[v] - want[v]).norm() / want[v].norm()).item()
+    assert torch.isfinite(got).all() and 0 < rel <= 2e-2, rel
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("S,lens", [(200, (200, 137, 70, 1)), (48, (48, 20)), (384, (384, 384))])
 def test_hf_attention_seam_runs_the_third_party_modernbert_on_the_hip_kernels(S, lens):
